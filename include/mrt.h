@@ -1,0 +1,152 @@
+/*
+ * mrt.h -- C ABI of the MI355X ray/scene intersection path ("mrt" = MI355X ray tracer).
+ *
+ * The reference program has no FFI layer: its boundary is the set of C++ member calls that
+ * game.cpp makes on its global Raytracer / Rasterizer / Camera objects.  Each entry point
+ * below names the reference call it stands in for (paths relative to the reference's
+ * Project/ directory).  All pointers are plain host pointers unless a parameter says
+ * "device"; no C++ or framework types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative MRT_E_* code otherwise;
+ *     mrt_last_error() gives the text of the last failure on that context.
+ *   - colours are 32-bit 0xAARRGGBB words (surface.h:16 Pixel); hit pixels have alpha 0 and
+ *     a miss is 0xff4c4c4c, exactly as the reference writes them.
+ *   - matrices are 16 floats, column-major (glm::mat4 memory layout), camera-to-world
+ *     (scenedata.h:136 Camera::transform).
+ *   - a context is bound to one GPU and is used from one thread at a time (the reference's
+ *     Render is not re-entrant either: threads.cpp:155-157 keeps its state in statics).
+ */
+#ifndef MRT_H_
+#define MRT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRT_VERSION 1
+
+/* error codes */
+#define MRT_OK            0
+#define MRT_E_ARG        -1   /* bad argument (null pointer, size not a multiple of 8, ...) */
+#define MRT_E_STATE      -2   /* call order (render before scene upload, ...) */
+#define MRT_E_HIP        -3   /* a HIP runtime call failed */
+#define MRT_E_NO_DEVICE  -4   /* no usable GPU: this library has no CPU fallback */
+#define MRT_E_LIMIT      -5   /* scene exceeds a documented limit (BVH depth, counts) */
+
+/* render flags (mrt_render / mrt_render_device) */
+#define MRT_MODE_PACKET     0u        /* Raytracer::Render: 64-ray packets + direct light (raytracer.cpp:420-463, 524-574) */
+#define MRT_MODE_RECURSIVE  1u        /* per-pixel GetColorFromSphere: reflection/refraction (raytracer.cpp:465-490, 575-664) */
+#define MRT_MODE_MASK       0xffu
+#define MRT_SPP_GRID(g)     (((uint32_t)(g) & 0xffu) << 8)   /* g in {1,2,4,8}: g*g samples per pixel */
+
+typedef struct mrt_ctx mrt_ctx;
+
+/* One mesh, as scenedata.h:143-167 Mesh exposes it to Raytracer::BuildBVH, plus the three
+ * material scalars that BVH::BVH assigns per mesh (raytracer.cpp:908-929). */
+typedef struct mrt_mesh {
+    const float*   pos;         /* verts x 3, object space = world space */
+    const float*   uv;          /* verts x 2 (v already flipped, scenedata.cpp:181) */
+    const float*   tri_normal;  /* tris x 3, unit face normals (scenedata.cpp:251-256) */
+    const int32_t* tri;         /* tris x 3 vertex indices */
+    int32_t verts, tris;
+    int32_t texture_id;         /* index into the textures array, -1 = none (not traceable) */
+    float   refl, refr, rindex; /* Object::m_Refl / m_Refr / m_RIndex (raytracer.h:76-78) */
+} mrt_mesh;
+
+/* One paletted texture, as surface.h:41-55 Surface8 holds it after loading a .bin cache
+ * (surface.cpp:46-59): width*height palette indices and 32 pre-scaled 256-entry palettes. */
+typedef struct mrt_texture {
+    const uint8_t*  indices;    /* width x height */
+    const uint32_t* palettes;   /* 32 x 256, 0x00RRGGBB */
+    int32_t width, height;
+} mrt_texture;
+
+/* ---- life cycle --------------------------------------------------------------------- */
+
+/* Raytracer::Init + Rasterizer::Init (game.cpp:17-18; raytracer.cpp:384-413, rasterizer.cpp:21-46).
+ * width/height must be multiples of 8 (game.h:8-9).  device = GPU ordinal, -1 = the current
+ * one.  Creates the default light (0,5,0)/(1,1,1,1).  Fails with MRT_E_NO_DEVICE without a GPU. */
+int  mrt_create(int width, int height, int device, mrt_ctx** out);
+void mrt_destroy(mrt_ctx* ctx);
+const char* mrt_last_error(const mrt_ctx* ctx);   /* ctx may be NULL: last error of mrt_create */
+int  mrt_version(void);
+
+/* ---- scene -------------------------------------------------------------------------- */
+
+/* Raytracer::BuildBVH(meshList) (game.cpp:34; raytracer.cpp:670-673, 897-944): flattens the
+ * meshes into the reference's triangle order, builds the identical BVH on the host, converts
+ * it to the device layout and uploads it.  Mesh data is copied (as raytracer.h:158-170 does). */
+int mrt_scene_upload(mrt_ctx* ctx, const mrt_mesh* meshes, int n_meshes,
+                     const mrt_texture* textures, int n_textures);
+
+/* Raytracer::m_Lights (raytracer.h:244; game.cpp:69-70 moves light 0): n records of
+ * {pos.xyz, colour.xyzw} = 7 floats, colour in the reference's x=A,y=R,z=G,w=B order. */
+int mrt_set_lights(mrt_ctx* ctx, const float* pos_rgba7, int n);
+
+/* Host-only BVH build with the arrays handed back, for inspection and tests; needs no GPU
+ * and no context.  BVH::BVH + BVHNode::Subdivide (raytracer.cpp:897-1203).
+ *   node_minmax   : (2*tris+4) x 6 floats   {min.xyz, max.xyz}        (raytracer.h:251-255)
+ *   node_first_cnt: (2*tris+4) x 2 uint32   {firstLeft, count}        (raytracer.h:331-332)
+ *   tri_idx       : tris uint32             BVH::m_TriangleIdx        (raytracer.h:357)
+ *   info[4]       : nTris, nNodes (allocated), final poolPtr, maxDepth
+ * Slots 1 and 2 of the node arrays are unused, as in the reference (poolPtr starts at 2). */
+int mrt_bvh_build_host(const mrt_mesh* meshes, int n_meshes,
+                       float* node_minmax, uint32_t* node_first_cnt, uint32_t* tri_idx, int64_t* info);
+
+/* ---- rendering ---------------------------------------------------------------------- */
+
+/* Raytracer::Render(camera) (game.cpp:91; raytracer.cpp:420-463 with threads.cpp:158-225).
+ * Synchronous.  fb: host, height rows of pitch_px pixels, every pixel of every tile is
+ * written.  hit_ids: optional host array width*height (times g*g with MRT_SPP_GRID(g)),
+ * the primary ray's triangle index into the flattened triangle list, -1 = miss. */
+int mrt_render(mrt_ctx* ctx, const float cam_to_world[16], uint32_t flags,
+               uint32_t* fb, int pitch_px, int32_t* hit_ids);
+
+/* Same frame, device-resident and asynchronous: renders tile rows [y_begin, y_end) (multiples
+ * of 8) into DEVICE memory fb_dev (row y at fb_dev + y*pitch_px) on `stream` (a hipStream_t,
+ * NULL = the default stream) and returns without synchronising.  This is the launch the
+ * tile scheduler of threads.cpp:158-169 / raytracer.cpp:436-457 is replaced by; a multi-GPU
+ * caller gives each rank its own row band.  hit_ids_dev optional (device, full-frame indexing). */
+int mrt_render_device(mrt_ctx* ctx, const float cam_to_world[16], uint32_t flags,
+                      int y_begin, int y_end, void* fb_dev, int pitch_px,
+                      void* hit_ids_dev, void* stream);
+
+/* Rasterizer::Render(camera) (game.cpp:93; rasterizer.cpp:53-184).  fb as above; zbuf
+ * optional host width*height floats receiving the 1/z buffer (rasterizer.cpp:12,55);
+ * tri_ids optional host width*height, depth-winner triangle index, -1 = uncovered.
+ * Pixels no triangle covers are left untouched in fb (the reference clears before: game.cpp:87). */
+int mrt_raster_render(mrt_ctx* ctx, const float cam_to_world[16],
+                      uint32_t* fb, int pitch_px, float* zbuf, int32_t* tri_ids);
+
+/* ---- operator-level seam ------------------------------------------------------------ */
+
+/* BVH::TraverseRayPacket (raytracer.h:352; raytracer.cpp:1349-1464) on caller-made packets.
+ * Arrays are host, packet-major: O/D/rD n_packets x 64 x 3 floats, t n_packets x 64 (in: ray
+ * length, out: hit distance), out tri n_packets x 64 (-1 = none), u, v n_packets x 64. */
+int mrt_trace_packets(mrt_ctx* ctx, int n_packets, const float* O, const float* D, const float* rD,
+                      float* t, int32_t* tri, float* u, float* v);
+
+/* BVH::Traverse (raytracer.h:350; raytracer.cpp:945-950, 1204-1264) on n single rays,
+ * including the root gate exactly as the reference evaluates it.  O/D n x 3, t n (in/out). */
+int mrt_trace_rays(mrt_ctx* ctx, int n_rays, const float* O, const float* D,
+                   float* t, int32_t* tri, float* u, float* v);
+
+/* ---- measurement -------------------------------------------------------------------- */
+
+/* Ray counts of the most recent completed render on this context (device counters):
+ * out[0] primary rays, out[1] shadow rays, out[2] reflection+refraction rays,
+ * out[3] primary hits.  Synchronises the context's last stream. */
+int mrt_get_ray_counts(mrt_ctx* ctx, uint64_t out[4]);
+
+/* Camera::LookAt (scenedata.h:129-134): out = inverse(lookAt(pos, target, (0,1,0))) with the
+ * vendored glm's operation order, so callers can form bit-identical camera matrices. */
+void mrt_camera_look_at(const float pos[3], const float target[3], float out_cam_to_world[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRT_H_ */

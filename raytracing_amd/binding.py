@@ -1,0 +1,225 @@
+"""ctypes binding of libmrt.so, the C ABI declared in include/mrt.h.
+
+The classes mirror the objects game.cpp drives (game.cpp:7-9, 15-35, 84-93): ``Raytracer``
+(Init / BuildBVH / Render), ``Camera`` (SetPosition / LookAt) and a ``Surface`` framebuffer
+that is simply a numpy ``uint32`` array.  There is no CPU fallback: loading fails loudly when
+the library is missing, and creating a ``Raytracer`` fails when no GPU is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmrt.so")
+
+MODE_PACKET = 0
+MODE_RECURSIVE = 1
+
+SYMBOLS = ("mrt_create", "mrt_destroy", "mrt_last_error", "mrt_version", "mrt_scene_upload", "mrt_set_lights",
+           "mrt_bvh_build_host", "mrt_render", "mrt_render_device", "mrt_raster_render", "mrt_trace_packets",
+           "mrt_trace_rays", "mrt_get_ray_counts", "mrt_camera_look_at")
+
+
+class MrtError(RuntimeError):
+    pass
+
+
+class _Mesh(C.Structure):
+    _fields_ = [("pos", C.c_void_p), ("uv", C.c_void_p), ("tri_normal", C.c_void_p), ("tri", C.c_void_p),
+                ("verts", C.c_int32), ("tris", C.c_int32), ("texture_id", C.c_int32),
+                ("refl", C.c_float), ("refr", C.c_float), ("rindex", C.c_float)]
+
+
+class _Texture(C.Structure):
+    _fields_ = [("indices", C.c_void_p), ("palettes", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libmrt.so (built in-tree by raytracing_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MrtError("%s is missing: build it with `make -C raytracing_amd/csrc` (hipcc, gfx950)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, i32 = C.c_void_p, C.c_int
+        L.mrt_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+        L.mrt_destroy.argtypes = [vp]
+        L.mrt_destroy.restype = None
+        L.mrt_last_error.argtypes = [vp]
+        L.mrt_last_error.restype = C.c_char_p
+        L.mrt_scene_upload.argtypes = [vp, C.POINTER(_Mesh), i32, C.POINTER(_Texture), i32]
+        L.mrt_set_lights.argtypes = [vp, vp, i32]
+        L.mrt_bvh_build_host.argtypes = [C.POINTER(_Mesh), i32, vp, vp, vp, vp]
+        L.mrt_render.argtypes = [vp, vp, C.c_uint32, vp, i32, vp]
+        L.mrt_render_device.argtypes = [vp, vp, C.c_uint32, i32, i32, vp, i32, vp, vp]
+        L.mrt_raster_render.argtypes = [vp, vp, vp, i32, vp, vp]
+        L.mrt_trace_packets.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
+        L.mrt_trace_rays.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+        L.mrt_get_ray_counts.argtypes = [vp, vp]
+        L.mrt_camera_look_at.argtypes = [vp, vp, vp]
+        L.mrt_camera_look_at.restype = None
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def flags(mode=MODE_PACKET, spp_grid=1):
+    return (mode & 0xFF) | ((spp_grid & 0xFF) << 8)
+
+
+def _pack_scene(scene):
+    """Build the mrt_mesh / mrt_texture arrays; returns (meshes, textures, keepalive)."""
+    keep = []
+    meshes = (_Mesh * len(scene["meshes"]))()
+    for i, m in enumerate(scene["meshes"]):
+        pos = np.ascontiguousarray(m["pos"], np.float32)
+        uv = np.ascontiguousarray(m["uv"], np.float32)
+        N = np.ascontiguousarray(m["N"], np.float32)
+        tri = np.ascontiguousarray(m["tri"], np.int32)
+        keep += [pos, uv, N, tri]
+        meshes[i] = _Mesh(_p(pos), _p(uv), _p(N), _p(tri), pos.size // 3, N.size // 3, int(m["texture"]),
+                          float(m["refl"]), float(m["refr"]), float(m["rindex"]))
+    textures = (_Texture * max(1, len(scene["textures"])))()
+    for i, t in enumerate(scene["textures"]):
+        idx = np.ascontiguousarray(t["idx"], np.uint8)
+        pal = np.ascontiguousarray(t["pal"], np.uint32)
+        keep += [idx, pal]
+        textures[i] = _Texture(_p(idx), _p(pal), int(t["w"]), int(t["h"]))
+    return meshes, textures, keep
+
+
+def bvh_build_host(scene):
+    """BVH::BVH on the host (no GPU needed): returns dict(info, node_minmax, node_first_cnt, tri_idx)."""
+    L = lib()
+    meshes, _, keep = _pack_scene(scene)
+    ntris = sum(len(m["N"]) for m in scene["meshes"])
+    slots = 2 * ntris + 4
+    mm = np.zeros((slots, 6), np.float32)
+    fc = np.zeros((slots, 2), np.uint32)
+    idx = np.zeros(max(1, ntris), np.uint32)
+    info = np.zeros(4, np.int64)
+    rc = L.mrt_bvh_build_host(meshes, len(scene["meshes"]), _p(mm), _p(fc), _p(idx), _p(info))
+    if rc != 0:
+        raise MrtError("mrt_bvh_build_host: %s" % L.mrt_last_error(None).decode())
+    del keep
+    return {"nTris": int(info[0]), "nNodes": int(info[1]), "poolPtr": int(info[2]), "maxDepth": int(info[3]),
+            "node_minmax": mm, "node_first_cnt": fc, "tri_idx": idx[:ntris]}
+
+
+class Camera:
+    """scenedata.h:125-137: a camera-to-world matrix (column-major) with SetPosition / LookAt."""
+
+    def __init__(self):
+        self.transform = np.eye(4, dtype=np.float32).reshape(16)
+
+    def set_position(self, pos):
+        self.transform[12:15] = np.asarray(pos, np.float32)
+
+    def get_position(self):
+        return self.transform[12:15].copy()
+
+    def look_at(self, target):
+        out = np.zeros(16, np.float32)
+        lib().mrt_camera_look_at(_p(self.get_position()), _p(np.asarray(target, np.float32)), _p(out))
+        self.transform = out
+
+
+class Raytracer:
+    """The reference's Raytracer + Rasterizer pair behind the C ABI (game.cpp:17-19, 34, 91-93)."""
+
+    def __init__(self, width, height, device=-1):
+        self.L = lib()
+        self.width, self.height = width, height
+        h = C.c_void_p()
+        rc = self.L.mrt_create(width, height, device, C.byref(h))
+        if rc != 0:
+            raise MrtError("mrt_create failed (%d): %s" % (rc, self.L.mrt_last_error(None).decode()))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mrt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise MrtError("%s failed (%d): %s" % (what, rc, self.L.mrt_last_error(self.h).decode()))
+
+    def build_bvh(self, scene):
+        """Raytracer::BuildBVH(meshList): flatten, build, upload."""
+        meshes, textures, keep = _pack_scene(scene)
+        self._check(self.L.mrt_scene_upload(self.h, meshes, len(scene["meshes"]), textures, len(scene["textures"])),
+                    "mrt_scene_upload")
+        del keep
+
+    def set_lights(self, lights):
+        a = np.ascontiguousarray(lights, np.float32).reshape(-1, 7)
+        self._check(self.L.mrt_set_lights(self.h, _p(a), len(a)), "mrt_set_lights")
+
+    def render(self, cam, mode=MODE_PACKET, spp_grid=1, want_ids=True, fb=None):
+        """Raytracer::Render(camera) into a host framebuffer; returns (fb, hit_ids)."""
+        cam = np.ascontiguousarray(getattr(cam, "transform", cam), np.float32).reshape(16)
+        if fb is None:
+            fb = np.zeros((self.height, self.width), np.uint32)
+        g = max(1, spp_grid)
+        ids = np.full((self.height * g, self.width * g), -2, np.int32) if want_ids else None
+        self._check(self.L.mrt_render(self.h, _p(cam), flags(mode, spp_grid), _p(fb), fb.strides[0] // 4, _p(ids)), "mrt_render")
+        return fb, ids
+
+    def render_device(self, cam, fb_ptr, pitch, mode=MODE_PACKET, spp_grid=1, rows=None, ids_ptr=None, stream=None):
+        """Asynchronous launch into device memory (raw pointers, e.g. torch.Tensor.data_ptr())."""
+        cam = np.ascontiguousarray(getattr(cam, "transform", cam), np.float32).reshape(16)
+        y0, y1 = rows if rows else (0, self.height)
+        self._check(self.L.mrt_render_device(self.h, _p(cam), flags(mode, spp_grid), y0, y1, C.c_void_p(fb_ptr), pitch,
+                                             C.c_void_p(ids_ptr) if ids_ptr else None,
+                                             C.c_void_p(stream) if stream else None), "mrt_render_device")
+
+    def ray_counts(self):
+        out = np.zeros(4, np.uint64)
+        self._check(self.L.mrt_get_ray_counts(self.h, _p(out)), "mrt_get_ray_counts")
+        return {"primary": int(out[0]), "shadow": int(out[1]), "secondary": int(out[2]), "primary_hits": int(out[3])}
+
+    def raster(self, cam, fb=None, want_z=True, want_ids=True):
+        """Rasterizer::Render(camera)."""
+        cam = np.ascontiguousarray(getattr(cam, "transform", cam), np.float32).reshape(16)
+        if fb is None:
+            fb = np.zeros((self.height, self.width), np.uint32)
+        z = np.zeros((self.height, self.width), np.float32) if want_z else None
+        ids = np.full((self.height, self.width), -1, np.int32) if want_ids else None
+        self._check(self.L.mrt_raster_render(self.h, _p(cam), _p(fb), fb.strides[0] // 4, _p(z), _p(ids)), "mrt_raster_render")
+        return fb, z, ids
+
+    def trace_packets(self, O, D, rD, t):
+        """BVH::TraverseRayPacket on (n_packets, 64, 3) ray arrays; returns (t, tri, u, v)."""
+        O = np.ascontiguousarray(O, np.float32)
+        D = np.ascontiguousarray(D, np.float32)
+        rD = np.ascontiguousarray(rD, np.float32)
+        t = np.array(t, np.float32, copy=True).reshape(-1, 64)
+        n = t.shape[0]
+        tri = np.zeros((n, 64), np.int32)
+        u = np.zeros((n, 64), np.float32)
+        v = np.zeros((n, 64), np.float32)
+        self._check(self.L.mrt_trace_packets(self.h, n, _p(O), _p(D), _p(rD), _p(t), _p(tri), _p(u), _p(v)), "mrt_trace_packets")
+        return t, tri, u, v
+
+    def trace_rays(self, O, D, t):
+        """BVH::Traverse on (n, 3) ray arrays; returns (t, tri, u, v)."""
+        O = np.ascontiguousarray(O, np.float32)
+        D = np.ascontiguousarray(D, np.float32)
+        t = np.array(t, np.float32, copy=True).reshape(-1)
+        n = t.shape[0]
+        tri = np.zeros(n, np.int32)
+        u = np.zeros(n, np.float32)
+        v = np.zeros(n, np.float32)
+        self._check(self.L.mrt_trace_rays(self.h, n, _p(O), _p(D), _p(t), _p(tri), _p(u), _p(v)), "mrt_trace_rays")
+        return t, tri, u, v

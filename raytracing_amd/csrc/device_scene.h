@@ -1,0 +1,58 @@
+// Device-side views of the flattened scene and of one frame, passed to the kernels by value.
+//
+// HBM layout (all arrays 16-byte aligned, uploaded once per mrt_scene_upload):
+//   nodes : 2 x float4 per node slot i, the reference's 32-byte BVHNode (raytracer.h:327-341):
+//             [2i]   = {min.x, min.y, min.z, bits(firstLeft)}
+//             [2i+1] = {max.x, max.y, max.z, bits(count)}
+//           An inner node's two children are slots firstLeft and firstLeft+1, i.e. 64
+//           contiguous bytes.  For a leaf, firstLeft is the first record in `ltri`.
+//   ltri  : 3 x float4 per LEAF-ORDER slot k (position in BVH::m_TriangleIdx), so a leaf's
+//           triangles are contiguous and are read front to back like the reference does:
+//             [3k]   = {p0.x, p0.y, p0.z, bits(triangle id)}
+//             [3k+1] = {e1 = p1-p0, 0}      (the subtraction Triangle::Intersect performs first)
+//             [3k+2] = {e2 = p2-p0, 0}
+//   attr  : 4 x float4 per triangle ID (shading only, touched once per hit):
+//             [4t]   = {normal.xyz, refl}
+//             [4t+1] = {uv0.x, uv0.y, uv1.x, uv1.y}
+//             [4t+2] = {uv2.x, uv2.y, refr, rindex}
+//             [4t+3] = {bits(texture id), 0, 0, 0}
+//   tex   : int4 per texture {offset of its texels in `texels`, width, height, 0}
+//   texels: all palette-index bytes back to back
+//   pal   : 32 x 256 uint32 per texture (surface.h:53), level 15 is what the tracer reads
+//   lights: 8 floats per light {pos.xyz, pad, colour.xyzw}
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mrt {
+
+struct SceneDev {
+    const float4* nodes;
+    const float4* ltri;
+    const float4* attr;
+    const int4* tex;
+    const uint8_t* texels;
+    const uint32_t* pal;
+    const float4* lights;     // 2 float4 per light
+    int n_lights;
+    int n_tris;
+    int n_textures;
+};
+
+struct FrameDev {
+    float p0[3], d10[3], d20[3], cam[3];   // view-plane corner, p1-p0, p2-p0, eye (raytracer.cpp:422-434)
+    float inv_w, inv_h;
+    int width, height;       // of the traced image (output size times the supersampling grid)
+    int tiles_x;             // width / 8
+    int tile_y0;             // first tile row of this launch
+    int n_tiles;             // tiles in this launch
+    int grid_g;              // supersampling grid g: 1, 2, 4 or 8
+    int pitch;               // output row pitch in pixels
+    uint32_t* fb;            // output frame (output resolution)
+    int32_t* hit_ids;        // optional, traced-image resolution
+    unsigned long long* counters;   // [0] primary rays [1] shadow rays [2] secondary rays [3] primary hits
+};
+
+constexpr int kStackDepth = 64;   // per-ray traversal stack entries; BVH depth must stay below
+
+}  // namespace mrt

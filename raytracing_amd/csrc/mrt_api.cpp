@@ -1,0 +1,404 @@
+// C ABI of the ray path (include/mrt.h): context, scene upload, frame launches.
+// Host code only; the kernels live in kernels.hip and raster.hip.  There is no CPU fallback:
+// without a GPU mrt_create fails and nothing else can be called.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mrt.h"
+#include "bvh_builder.h"
+#include "device_scene.h"
+#include "mrt_math.h"
+#include "raster.h"
+
+namespace mrt {
+hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, int stack_entries, hipStream_t stream);
+hipError_t launch_trace_packets(const SceneDev& S, int n_packets, const float* O, const float* D, const float* rD,
+                                float* t, int32_t* tri, float* u, float* v, hipStream_t stream);
+hipError_t launch_trace_rays(const SceneDev& S, int n_rays, int stack_entries, const float* O, const float* D,
+                             float* t, int32_t* tri, float* u, float* v, hipStream_t stream);
+}  // namespace mrt
+
+using namespace mrt;
+
+namespace {
+thread_local std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t count) {
+        if (count <= n && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t upload(const std::vector<T>& v, hipStream_t s) {
+        hipError_t e = ensure(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+}  // namespace
+
+struct mrt_ctx {
+    int width = 0, height = 0, device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // scene
+    bool has_scene = false;
+    int stack_entries = 16;
+    HostBVH bvh;
+    DevBuf<float4> d_nodes, d_ltri, d_attr, d_lights;
+    DevBuf<int4> d_tex;
+    DevBuf<uint8_t> d_texels;
+    DevBuf<uint32_t> d_pal;
+    std::vector<float4> lights;     // 2 per light
+    SceneDev scene{};
+    // frame outputs of the synchronous entry points
+    DevBuf<uint32_t> d_fb;
+    DevBuf<int32_t> d_ids;
+    DevBuf<unsigned long long> d_counters;
+    hipStream_t last_stream = nullptr;
+    // rasterizer
+    RasterState raster;
+};
+
+namespace {
+
+int fail(mrt_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+#define MRT_HIP(c, call)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return fail((c), MRT_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+void refresh_scene_view(mrt_ctx* c) {
+    SceneDev& S = c->scene;
+    S.nodes = c->d_nodes.p; S.ltri = c->d_ltri.p; S.attr = c->d_attr.p;
+    S.tex = c->d_tex.p; S.texels = c->d_texels.p; S.pal = c->d_pal.p;
+    S.lights = c->d_lights.p;
+    S.n_lights = (int)(c->lights.size() / 2);
+    S.n_tris = (int)c->bvh.n_tris;
+}
+
+// Raytracer::Render's view-plane set-up (raytracer.cpp:422-434) for a traced image of w x h
+void fill_view(FrameDev& F, const float cam16[16], int w, int h) {
+    m4 cam;
+    memcpy(&cam, cam16, 64);
+    const float fov = 1.8f;
+    const float aspect = (float)h / (float)w;          // game.h:5
+    const f4 a = mul(cam, f4{-1, aspect, -fov, 1});
+    const f4 b = mul(cam, f4{1, aspect, -fov, 1});
+    const f4 d = mul(cam, f4{-1, -aspect, -fov, 1});
+    const f3 p0 = {a.x, a.y, a.z}, p1 = {b.x, b.y, b.z}, p2 = {d.x, d.y, d.z};
+    const f3 d10 = p1 - p0, d20 = p2 - p0;
+    F.p0[0] = p0.x; F.p0[1] = p0.y; F.p0[2] = p0.z;
+    F.d10[0] = d10.x; F.d10[1] = d10.y; F.d10[2] = d10.z;
+    F.d20[0] = d20.x; F.d20[1] = d20.y; F.d20[2] = d20.z;
+    F.cam[0] = cam.c[3].x; F.cam[1] = cam.c[3].y; F.cam[2] = cam.c[3].z;   // scenedata.h:130
+    F.inv_h = 1.0f / (float)h;
+    F.inv_w = 1.0f / (float)w;
+    F.width = w; F.height = h;
+    F.tiles_x = w / 8;
+}
+
+int parse_flags(mrt_ctx* c, uint32_t flags, int& mode, int& g) {
+    mode = (int)(flags & MRT_MODE_MASK);
+    g = (int)((flags >> 8) & 0xffu);
+    if (g == 0) g = 1;
+    if (mode != (int)MRT_MODE_PACKET && mode != (int)MRT_MODE_RECURSIVE) return fail(c, MRT_E_ARG, "unknown render mode");
+    if (g != 1 && g != 2 && g != 4 && g != 8) return fail(c, MRT_E_ARG, "supersampling grid must be 1, 2, 4 or 8");
+    return MRT_OK;
+}
+
+int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, int y_end, uint32_t* fb_dev,
+                  int pitch_px, int32_t* ids_dev, hipStream_t stream) {
+    int mode, g;
+    if (int rc = parse_flags(c, flags, mode, g)) return rc;
+    if (!c->has_scene) return fail(c, MRT_E_STATE, "mrt_scene_upload has not been called");
+    if (!cam || !fb_dev) return fail(c, MRT_E_ARG, "null camera or framebuffer");
+    if (y_begin < 0 || y_end > c->height || y_begin > y_end || (y_begin % 8) || (y_end % 8))
+        return fail(c, MRT_E_ARG, "row band must be multiples of 8 inside the frame");
+    if (pitch_px < c->width) return fail(c, MRT_E_ARG, "pitch smaller than width");
+    FrameDev F{};
+    fill_view(F, cam, c->width * g, c->height * g);
+    F.grid_g = g;
+    F.tile_y0 = y_begin * g / 8;
+    F.n_tiles = ((y_end - y_begin) * g / 8) * F.tiles_x;
+    F.pitch = pitch_px;
+    F.fb = fb_dev;
+    F.hit_ids = ids_dev;
+    F.counters = c->d_counters.p;
+    MRT_HIP(c, hipMemsetAsync(c->d_counters.p, 0, 4 * sizeof(unsigned long long), stream));
+    MRT_HIP(c, launch_render(c->scene, F, mode, c->stack_entries, stream));
+    c->last_stream = stream;
+    return MRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrt_version(void) { return MRT_VERSION; }
+
+const char* mrt_last_error(const mrt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mrt_create(int width, int height, int device, mrt_ctx** out) {
+    if (!out) return fail(nullptr, MRT_E_ARG, "out is null");
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || (width % 8) || (height % 8))
+        return fail(nullptr, MRT_E_ARG, "width and height must be positive multiples of 8");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(nullptr, MRT_E_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    if (device >= n) return fail(nullptr, MRT_E_ARG, "device ordinal out of range");
+    MRT_HIP(nullptr, hipSetDevice(device));
+    mrt_ctx* c = new mrt_ctx();
+    c->width = width; c->height = height; c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = c->d_counters.ensure(4);
+    if (e != hipSuccess) {
+        std::string msg = std::string("context set-up: ") + hipGetErrorString(e);
+        delete c;
+        return fail(nullptr, MRT_E_HIP, msg);
+    }
+    // the one light Raytracer::Init creates (raytracer.cpp:396-399)
+    c->lights = {make_float4(0, 5, 0, 0), make_float4(1, 1, 1, 1)};
+    *out = c;
+    return MRT_OK;
+}
+
+void mrt_destroy(mrt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    if (c->last_stream) { (void)hipStreamSynchronize(c->last_stream); }
+    c->d_nodes.release(); c->d_ltri.release(); c->d_attr.release(); c->d_lights.release();
+    c->d_tex.release(); c->d_texels.release(); c->d_pal.release();
+    c->d_fb.release(); c->d_ids.release(); c->d_counters.release();
+    raster_release(c->raster);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mrt_set_lights(mrt_ctx* c, const float* pos_rgba7, int n) {
+    if (!c) return MRT_E_ARG;
+    if (n < 0 || (n > 0 && !pos_rgba7)) return fail(c, MRT_E_ARG, "bad light array");
+    MRT_HIP(c, hipSetDevice(c->device));
+    c->lights.clear();
+    for (int i = 0; i < n; ++i) {
+        const float* p = pos_rgba7 + 7 * i;
+        c->lights.push_back(make_float4(p[0], p[1], p[2], 0));
+        c->lights.push_back(make_float4(p[3], p[4], p[5], p[6]));
+    }
+    MRT_HIP(c, c->d_lights.upload(c->lights, c->stream));
+    MRT_HIP(c, hipStreamSynchronize(c->stream));
+    refresh_scene_view(c);
+    return MRT_OK;
+}
+
+int mrt_scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures) {
+    if (!c) return MRT_E_ARG;
+    if (n_textures < 0 || (n_textures > 0 && !textures)) return fail(c, MRT_E_ARG, "bad texture array");
+    for (int i = 0; i < n_textures; ++i)
+        if (!textures[i].indices || !textures[i].palettes || textures[i].width <= 0 || textures[i].height <= 0)
+            return fail(c, MRT_E_ARG, "bad texture");
+    MRT_HIP(c, hipSetDevice(c->device));
+    std::string err;
+    c->has_scene = false;
+    if (!flatten_meshes(meshes, n_meshes, n_textures, true, c->bvh.tris, err)) return fail(c, MRT_E_ARG, err);
+    build_bvh(c->bvh);
+    const HostBVH& B = c->bvh;
+    if (B.max_depth + 2 > kStackDepth) return fail(c, MRT_E_LIMIT, "BVH deeper than the traversal stack (62 levels)");
+    if (B.pool_ptr >= (1u << 26)) return fail(c, MRT_E_LIMIT, "too many BVH nodes for the packet work list encoding");
+    c->stack_entries = B.max_depth + 2;
+
+    // nodes: slots 0..pool_ptr (1 and 2 unused); leaves point into the leaf-ordered records
+    const size_t slots = (size_t)B.pool_ptr + 1;
+    std::vector<float4> nodes(2 * slots);
+    for (size_t i = 0; i < slots; ++i) {
+        nodes[2 * i] = make_float4(B.nmin[i].x, B.nmin[i].y, B.nmin[i].z, bits2f(B.first[i]));
+        nodes[2 * i + 1] = make_float4(B.nmax[i].x, B.nmax[i].y, B.nmax[i].z, bits2f(B.count[i]));
+    }
+    std::vector<float4> ltri(3 * (size_t)B.n_tris), attr(4 * (size_t)B.n_tris);
+    for (uint32_t k = 0; k < B.n_tris; ++k) {
+        const uint32_t id = B.idx[k];
+        const HostTri& t = B.tris[id];
+        const f3 e1 = t.p1 - t.p0, e2 = t.p2 - t.p0;      // raytracer.cpp:289-290
+        ltri[3 * (size_t)k] = make_float4(t.p0.x, t.p0.y, t.p0.z, bits2f(id));
+        ltri[3 * (size_t)k + 1] = make_float4(e1.x, e1.y, e1.z, 0);
+        ltri[3 * (size_t)k + 2] = make_float4(e2.x, e2.y, e2.z, 0);
+    }
+    for (uint32_t id = 0; id < B.n_tris; ++id) {
+        const HostTri& t = B.tris[id];
+        attr[4 * (size_t)id] = make_float4(t.normal.x, t.normal.y, t.normal.z, t.refl);
+        attr[4 * (size_t)id + 1] = make_float4(t.uv0.x, t.uv0.y, t.uv1.x, t.uv1.y);
+        attr[4 * (size_t)id + 2] = make_float4(t.uv2.x, t.uv2.y, t.refr, t.rindex);
+        attr[4 * (size_t)id + 3] = make_float4(bits2f((uint32_t)t.tex), 0, 0, 0);
+    }
+    std::vector<int4> tex(n_textures);
+    std::vector<uint8_t> texels;
+    std::vector<uint32_t> pal((size_t)n_textures * 32 * 256);
+    for (int i = 0; i < n_textures; ++i) {
+        const size_t n = (size_t)textures[i].width * textures[i].height;
+        tex[i] = make_int4((int)texels.size(), textures[i].width, textures[i].height, 0);
+        texels.insert(texels.end(), textures[i].indices, textures[i].indices + n);
+        memcpy(pal.data() + (size_t)i * 32 * 256, textures[i].palettes, 32 * 256 * 4);
+        if (texels.size() > 0x7fffffffu) return fail(c, MRT_E_LIMIT, "textures exceed 2 GiB of texels");
+    }
+    MRT_HIP(c, c->d_nodes.upload(nodes, c->stream));
+    MRT_HIP(c, c->d_ltri.upload(ltri, c->stream));
+    MRT_HIP(c, c->d_attr.upload(attr, c->stream));
+    MRT_HIP(c, c->d_tex.upload(tex, c->stream));
+    MRT_HIP(c, c->d_texels.upload(texels, c->stream));
+    MRT_HIP(c, c->d_pal.upload(pal, c->stream));
+    MRT_HIP(c, c->d_lights.upload(c->lights, c->stream));
+    if (int rc = raster_upload(c->raster, meshes, n_meshes, c->stream, err)) return fail(c, rc, err);
+    MRT_HIP(c, hipStreamSynchronize(c->stream));
+    refresh_scene_view(c);
+    c->scene.n_textures = n_textures;
+    c->has_scene = true;
+    return MRT_OK;
+}
+
+int mrt_bvh_build_host(const mrt_mesh* meshes, int n_meshes, float* node_minmax, uint32_t* node_first_cnt,
+                       uint32_t* tri_idx, int64_t* info) {
+    if (!node_minmax || !node_first_cnt || !tri_idx || !info) return fail(nullptr, MRT_E_ARG, "null output array");
+    HostBVH B;
+    std::string err;
+    if (!flatten_meshes(meshes, n_meshes, 0, false, B.tris, err)) return fail(nullptr, MRT_E_ARG, err);
+    build_bvh(B);
+    const size_t slots = (size_t)B.n_nodes_alloc + 3;
+    for (size_t i = 0; i < slots; ++i) {
+        node_minmax[6 * i] = B.nmin[i].x; node_minmax[6 * i + 1] = B.nmin[i].y; node_minmax[6 * i + 2] = B.nmin[i].z;
+        node_minmax[6 * i + 3] = B.nmax[i].x; node_minmax[6 * i + 4] = B.nmax[i].y; node_minmax[6 * i + 5] = B.nmax[i].z;
+        node_first_cnt[2 * i] = B.first[i];
+        node_first_cnt[2 * i + 1] = B.count[i];
+    }
+    memcpy(tri_idx, B.idx.data(), sizeof(uint32_t) * B.n_tris);
+    info[0] = B.n_tris; info[1] = B.n_nodes_alloc; info[2] = B.pool_ptr; info[3] = B.max_depth;
+    return MRT_OK;
+}
+
+int mrt_render_device(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, int y_end, void* fb_dev,
+                      int pitch_px, void* hit_ids_dev, void* stream) {
+    if (!c) return MRT_E_ARG;
+    MRT_HIP(c, hipSetDevice(c->device));
+    return render_common(c, cam, flags, y_begin, y_end, (uint32_t*)fb_dev, pitch_px, (int32_t*)hit_ids_dev, (hipStream_t)stream);
+}
+
+int mrt_render(mrt_ctx* c, const float cam[16], uint32_t flags, uint32_t* fb, int pitch_px, int32_t* hit_ids) {
+    if (!c) return MRT_E_ARG;
+    if (!fb) return fail(c, MRT_E_ARG, "null framebuffer");
+    int mode, g;
+    if (int rc = parse_flags(c, flags, mode, g)) return rc;
+    MRT_HIP(c, hipSetDevice(c->device));
+    const size_t npx = (size_t)c->width * c->height;
+    MRT_HIP(c, c->d_fb.ensure(npx));
+    if (hit_ids) MRT_HIP(c, c->d_ids.ensure(npx * g * g));
+    if (int rc = render_common(c, cam, flags, 0, c->height, c->d_fb.p, c->width, hit_ids ? c->d_ids.p : nullptr, c->stream))
+        return rc;
+    MRT_HIP(c, hipMemcpy2DAsync(fb, (size_t)pitch_px * 4, c->d_fb.p, (size_t)c->width * 4, (size_t)c->width * 4,
+                                (size_t)c->height, hipMemcpyDeviceToHost, c->stream));
+    if (hit_ids)
+        MRT_HIP(c, hipMemcpyAsync(hit_ids, c->d_ids.p, npx * g * g * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    MRT_HIP(c, hipStreamSynchronize(c->stream));
+    return MRT_OK;
+}
+
+int mrt_get_ray_counts(mrt_ctx* c, uint64_t out[4]) {
+    if (!c || !out) return MRT_E_ARG;
+    MRT_HIP(c, hipSetDevice(c->device));
+    MRT_HIP(c, hipStreamSynchronize(c->last_stream));
+    unsigned long long tmp[4];
+    MRT_HIP(c, hipMemcpy(tmp, c->d_counters.p, sizeof(tmp), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out[i] = tmp[i];
+    return MRT_OK;
+}
+
+int mrt_trace_packets(mrt_ctx* c, int n_packets, const float* O, const float* D, const float* rD, float* t,
+                      int32_t* tri, float* u, float* v) {
+    if (!c) return MRT_E_ARG;
+    if (n_packets < 0 || !O || !D || !rD || !t || !tri || !u || !v) return fail(c, MRT_E_ARG, "null ray array");
+    if (!c->has_scene) return fail(c, MRT_E_STATE, "mrt_scene_upload has not been called");
+    if (n_packets == 0) return MRT_OK;
+    MRT_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)n_packets * 64;
+    DevBuf<float> dO, dD, dR, dt, du, dv;
+    DevBuf<int32_t> dtri;
+    int rc = MRT_OK;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; return e == hipSuccess; };
+    if (ok(dO.ensure(3 * n)) && ok(dD.ensure(3 * n)) && ok(dR.ensure(3 * n)) && ok(dt.ensure(n)) && ok(du.ensure(n)) &&
+        ok(dv.ensure(n)) && ok(dtri.ensure(n)) &&
+        ok(hipMemcpyAsync(dO.p, O, 12 * n, hipMemcpyHostToDevice, c->stream)) &&
+        ok(hipMemcpyAsync(dD.p, D, 12 * n, hipMemcpyHostToDevice, c->stream)) &&
+        ok(hipMemcpyAsync(dR.p, rD, 12 * n, hipMemcpyHostToDevice, c->stream)) &&
+        ok(hipMemcpyAsync(dt.p, t, 4 * n, hipMemcpyHostToDevice, c->stream)) &&
+        ok(launch_trace_packets(c->scene, n_packets, dO.p, dD.p, dR.p, dt.p, dtri.p, du.p, dv.p, c->stream)) &&
+        ok(hipMemcpyAsync(t, dt.p, 4 * n, hipMemcpyDeviceToHost, c->stream)) &&
+        ok(hipMemcpyAsync(tri, dtri.p, 4 * n, hipMemcpyDeviceToHost, c->stream)) &&
+        ok(hipMemcpyAsync(u, du.p, 4 * n, hipMemcpyDeviceToHost, c->stream)) &&
+        ok(hipMemcpyAsync(v, dv.p, 4 * n, hipMemcpyDeviceToHost, c->stream)))
+        ok(hipStreamSynchronize(c->stream));
+    if (e != hipSuccess) rc = fail(c, MRT_E_HIP, std::string("mrt_trace_packets: ") + hipGetErrorString(e));
+    (void)hipStreamSynchronize(c->stream);
+    dO.release(); dD.release(); dR.release(); dt.release(); du.release(); dv.release(); dtri.release();
+    return rc;
+}
+
+int mrt_trace_rays(mrt_ctx* c, int n_rays, const float* O, const float* D, float* t, int32_t* tri, float* u, float* v) {
+    if (!c) return MRT_E_ARG;
+    if (n_rays < 0 || !O || !D || !t || !tri || !u || !v) return fail(c, MRT_E_ARG, "null ray array");
+    if (!c->has_scene) return fail(c, MRT_E_STATE, "mrt_scene_upload has not been called");
+    if (n_rays == 0) return MRT_OK;
+    MRT_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)n_rays;
+    DevBuf<float> dO, dD, dt, du, dv;
+    DevBuf<int32_t> dtri;
+    int rc = MRT_OK;
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; return e == hipSuccess; };
+    if (ok(dO.ensure(3 * n)) && ok(dD.ensure(3 * n)) && ok(dt.ensure(n)) && ok(du.ensure(n)) && ok(dv.ensure(n)) &&
+        ok(dtri.ensure(n)) &&
+        ok(hipMemcpyAsync(dO.p, O, 12 * n, hipMemcpyHostToDevice, c->stream)) &&
+        ok(hipMemcpyAsync(dD.p, D, 12 * n, hipMemcpyHostToDevice, c->stream)) &&
+        ok(hipMemcpyAsync(dt.p, t, 4 * n, hipMemcpyHostToDevice, c->stream)) &&
+        ok(launch_trace_rays(c->scene, n_rays, c->stack_entries, dO.p, dD.p, dt.p, dtri.p, du.p, dv.p, c->stream)) &&
+        ok(hipMemcpyAsync(t, dt.p, 4 * n, hipMemcpyDeviceToHost, c->stream)) &&
+        ok(hipMemcpyAsync(tri, dtri.p, 4 * n, hipMemcpyDeviceToHost, c->stream)) &&
+        ok(hipMemcpyAsync(u, du.p, 4 * n, hipMemcpyDeviceToHost, c->stream)) &&
+        ok(hipMemcpyAsync(v, dv.p, 4 * n, hipMemcpyDeviceToHost, c->stream)))
+        ok(hipStreamSynchronize(c->stream));
+    if (e != hipSuccess) rc = fail(c, MRT_E_HIP, std::string("mrt_trace_rays: ") + hipGetErrorString(e));
+    (void)hipStreamSynchronize(c->stream);
+    dO.release(); dD.release(); dt.release(); du.release(); dv.release(); dtri.release();
+    return rc;
+}
+
+int mrt_raster_render(mrt_ctx* c, const float cam[16], uint32_t* fb, int pitch_px, float* zbuf, int32_t* tri_ids) {
+    if (!c) return MRT_E_ARG;
+    if (!cam || !fb) return fail(c, MRT_E_ARG, "null camera or framebuffer");
+    if (!c->has_scene) return fail(c, MRT_E_STATE, "mrt_scene_upload has not been called");
+    if (pitch_px < c->width) return fail(c, MRT_E_ARG, "pitch smaller than width");
+    MRT_HIP(c, hipSetDevice(c->device));
+    std::string err;
+    RasterTextures tx{c->d_tex.p, c->d_texels.p, c->d_pal.p};
+    if (int rc = raster_render(c->raster, tx, c->width, c->height, cam, fb, pitch_px, zbuf, tri_ids, c->stream, err))
+        return fail(c, rc, err);
+    return MRT_OK;
+}
+
+}  // extern "C"

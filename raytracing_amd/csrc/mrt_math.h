@@ -1,0 +1,98 @@
+// Vector arithmetic shared by the host code and the HIP kernels.
+//
+// Operation ORDER is part of the contract: results must be bit-identical to the reference,
+// which takes its math from glm 0.9.5.4 (paths below are relative to the reference's
+// Project/lib/glm/).  Build with -ffp-contract=off; never with fast-math.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MRT_HD __host__ __device__ __forceinline__
+#else
+#define MRT_HD inline
+#endif
+
+namespace mrt {
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+struct m4 { f4 c[4]; };   // column-major: c[i] is column i
+
+// detail/func_common.inl:367-399 -- compare + select, not fminf/fmaxf (NaN and +-0 differ)
+MRT_HD float gmin(float x, float y) { return x < y ? x : y; }
+MRT_HD float gmax(float x, float y) { return x > y ? x : y; }
+// detail/func_common.inl:403-415
+MRT_HD float gclamp(float x, float lo, float hi) { return gmin(hi, gmax(lo, x)); }
+
+// detail/type_vec3.inl:540-616, detail/type_vec4.inl:602-626 -- component-wise
+MRT_HD f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+MRT_HD f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+MRT_HD f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+MRT_HD f3 operator/(f3 a, f3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+MRT_HD f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+MRT_HD f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
+MRT_HD f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+MRT_HD f3 operator/(float s, f3 a) { return {s / a.x, s / a.y, s / a.z}; }
+MRT_HD f2 operator+(f2 a, f2 b) { return {a.x + b.x, a.y + b.y}; }
+MRT_HD f2 operator-(f2 a, f2 b) { return {a.x - b.x, a.y - b.y}; }
+MRT_HD f2 operator*(float s, f2 a) { return {s * a.x, s * a.y}; }
+MRT_HD f4 operator+(f4 a, f4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+MRT_HD f4 operator-(f4 a, f4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+MRT_HD f4 operator*(f4 a, f4 b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+MRT_HD f4 operator*(f4 a, float s) { return {a.x * s, a.y * s, a.z * s, a.w * s}; }
+MRT_HD f4 operator*(float s, f4 a) { return {s * a.x, s * a.y, s * a.z, s * a.w}; }
+MRT_HD f4 clamp01(f4 a) {
+    return {gclamp(a.x, 0.0f, 1.0f), gclamp(a.y, 0.0f, 1.0f), gclamp(a.z, 0.0f, 1.0f), gclamp(a.w, 0.0f, 1.0f)};
+}
+
+// detail/func_geometric.inl:66-73 -- three products, then (x + y) + z
+MRT_HD float dot(f3 a, f3 b) {
+    float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z;
+    return tx + ty + tz;
+}
+// detail/func_geometric.inl:215-228
+MRT_HD f3 cross(f3 x, f3 y) {
+    return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y};
+}
+// detail/func_geometric.inl:256-265 + detail/func_exponential.inl:226-229: IEEE sqrt, then an
+// IEEE divide, then three multiplies (not rsqrt)
+MRT_HD f3 normalize(f3 v) {
+    float sqr = v.x * v.x + v.y * v.y + v.z * v.z;
+    float r = 1.0f / sqrtf(sqr);
+    return v * r;
+}
+
+MRT_HD uint32_t f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+MRT_HD float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+// ---- host-side matrix helpers (camera set-up happens once per frame on the host) --------
+inline float& el(m4& m, int col, int row) { return (&m.c[col].x)[row]; }
+inline float el(const m4& m, int col, int row) { return (&m.c[col].x)[row]; }
+inline m4 identity() { return {{{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}}}; }
+// detail/type_mat4x4.inl:676-687 -- (m0*v0 + m1*v1) + (m2*v2 + m3*v3)
+inline f4 mul(const m4& m, f4 v) {
+    f4 a0 = m.c[0] * v.x + m.c[1] * v.y;
+    f4 a1 = m.c[2] * v.z + m.c[3] * v.w;
+    return a0 + a1;
+}
+// detail/type_mat4x4.inl:753-775
+inline m4 mul(const m4& a, const m4& b) {
+    m4 r;
+    for (int j = 0; j < 4; ++j)
+        r.c[j] = ((a.c[0] * b.c[j].x + a.c[1] * b.c[j].y) + a.c[2] * b.c[j].z) + a.c[3] * b.c[j].w;
+    return r;
+}
+// detail/type_mat3x3.inl:587-597 applied to the upper-left 3x3 of a mat4
+MRT_HD f3 mul3(const m4& m, f3 v) {
+    return {m.c[0].x * v.x + m.c[1].x * v.y + m.c[2].x * v.z,
+            m.c[0].y * v.x + m.c[1].y * v.y + m.c[2].y * v.z,
+            m.c[0].z * v.x + m.c[1].z * v.y + m.c[2].z * v.z};
+}
+m4 inverse(const m4& m);            // detail/type_mat4x4.inl:477-535
+m4 look_at(f3 eye, f3 center, f3 up);  // gtc/matrix_transform.inl:416-441
+
+}  // namespace mrt
