@@ -1210,6 +1210,28 @@ int ora_trace_ray(Context* c, const float* O3, const float* D3, float tmax, int 
     *t_out = r.t; uv_out[0] = h.u; uv_out[1] = h.v;
     return h.tri;
 }
+// batch forms of the two traversal operators, for parity tests on caller-made rays
+void ora_trace_packets(Context* c, int n_packets, const float* O, const float* D, const float* rD, float* t,
+                       int32_t* tri, float* u, float* v) {
+    for (int p = 0; p < n_packets; ++p) {
+        RayPacket pk; HitPacket res;
+        const size_t b = (size_t)p * PACKETSIZE;
+        memcpy(pk.O, O + 3 * b, sizeof(pk.O)); memcpy(pk.D, D + 3 * b, sizeof(pk.D));
+        memcpy(pk.rD, rD + 3 * b, sizeof(pk.rD)); memcpy(pk.t, t + b, sizeof(pk.t));
+        for (int i = 0; i < PACKETSIZE; ++i) { res.tri[i] = -1; res.u[i] = 0; res.v[i] = 0; }
+        bvh_traverse_packet(*c->bvh, pk, res);
+        memcpy(t + b, pk.t, sizeof(pk.t));
+        for (int i = 0; i < PACKETSIZE; ++i) { tri[b + i] = res.tri[i]; u[b + i] = res.u[i]; v[b + i] = res.v[i]; }
+    }
+}
+void ora_trace_rays(Context* c, int n, const float* O, const float* D, float* t, int32_t* tri, float* u, float* v) {
+    for (int i = 0; i < n; ++i) {
+        Ray r{{O[3 * i], O[3 * i + 1], O[3 * i + 2]}, {D[3 * i], D[3 * i + 1], D[3 * i + 2]}, t[i]};
+        HitRec h{-1, 0, 0};
+        bvh_traverse(*c->bvh, r, h);
+        t[i] = r.t; tri[i] = h.tri; u[i] = h.u; v[i] = h.v;
+    }
+}
 // brute force over all triangles in storage order (cross-check of the traversal)
 int ora_trace_ray_brute(Context* c, const float* O3, const float* D3, float tmax, float* t_out, float* uv_out) {
     vec3 O{O3[0], O3[1], O3[2]}, D{D3[0], D3[1], D3[2]};

@@ -6,6 +6,7 @@ that is simply a numpy ``uint32`` array.  There is no CPU fallback: loading fail
 the library is missing, and creating a ``Raytracer`` fails when no GPU is present.
 """
 import ctypes as C
+import importlib.util
 import os
 
 import numpy as np
@@ -38,12 +39,29 @@ class _Texture(C.Structure):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One process must hold ONE HIP runtime.  A PyTorch-ROCm wheel ships its own libamdhip64.so
+    and asks for it under a name the system copy does not answer to, so if libmrt.so pulled in
+    /opt/rocm's copy first, a later `import torch` would load a second runtime and find no GPU.
+    Loading torch's copy first (when torch is installed) lets both share it."""
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load libmrt.so (built in-tree by raytracing_amd/csrc/Makefile)."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise MrtError("%s is missing: build it with `make -C raytracing_amd/csrc` (hipcc, gfx950)" % LIB_PATH)
+        _preload_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         vp, i32 = C.c_void_p, C.c_int
         L.mrt_create.argtypes = [i32, i32, i32, C.POINTER(vp)]

@@ -1,0 +1,85 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(HERE, "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def known():
+    with open(os.path.join(GOLDEN, "known_answers.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def glm_vectors():
+    with open(os.path.join(GOLDEN, "glm_vectors.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def maze_scene():
+    from raytracing_amd import scene_io
+    return scene_io.load_scene(os.path.join(GOLDEN, "maze.mrts"))
+
+
+@pytest.fixture(scope="session")
+def maze_oracle(maze_scene):
+    import oracle_lib
+    o = oracle_lib.Oracle()
+    o.add_scene(maze_scene)
+    o.build_bvh()
+    o.set_threads(min(8, os.cpu_count() or 1))
+    return o
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def hexbits(a):
+    return ["%08x" % x for x in bits(a).reshape(-1)]
+
+
+def pose_matrix(pos, target):
+    import oracle_lib
+    return oracle_lib.lookat(pos, target)
+
+
+# camera poses used across the parity tests: (name, position, look-at target); None = identity
+POSES = [
+    ("P0_identity", None, None),
+    ("P1", (6, 3, 12), (0, 0, 0)),
+    ("P2", (3, 4, 10), (0, 0, 0)),
+    ("P3", (-10, 0.5, -12), (5, 0, 5)),
+    ("inside_wall", (8.18, 0.2, 5.15), (0, 0.2, 0)),
+    ("straight_down", (2, 9, 2), (2, 0, 2.0000001)),
+]
+
+
+def pose_cam(pose):
+    import oracle_lib
+    _, pos, target = pose
+    if pos is None:
+        return oracle_lib.IDENTITY.copy()
+    return oracle_lib.lookat(pos, target)
+
+
+def colour_mismatch_fraction(a, b):
+    """Fraction of pixels whose worst channel differs by more than 1/255."""
+    a8 = np.ascontiguousarray(a, np.uint32).view(np.uint8).reshape(-1, 4).astype(np.int16)
+    b8 = np.ascontiguousarray(b, np.uint32).view(np.uint8).reshape(-1, 4).astype(np.int16)
+    return float((np.abs(a8 - b8).max(axis=1) > 1).mean())

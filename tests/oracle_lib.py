@@ -59,6 +59,8 @@ def lib():
         L.ora_render.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
         L.ora_trace_ray.argtypes = [vp, vp, vp, f32, i32, vp, vp]
         L.ora_trace_ray_brute.argtypes = [vp, vp, vp, f32, vp, vp]
+        L.ora_trace_packets.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
+        L.ora_trace_rays.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
         L.ora_gen_ray.argtypes = [vp, i32, i32, i32, i32, vp, vp]
         L.ora_raster_render.argtypes = [vp, vp, i32, i32, vp, vp, vp]
         _lib = L
@@ -199,6 +201,29 @@ class Oracle:
         i = self.L.ora_trace_ray_brute(self.h, _p(np.asarray(O, np.float32)), _p(np.asarray(D, np.float32)), tmax,
                                        C.byref(t), _p(uv))
         return i, t.value, uv
+
+    def trace_packets(self, O, D, rD, t):
+        O = np.ascontiguousarray(O, np.float32)
+        D = np.ascontiguousarray(D, np.float32)
+        rD = np.ascontiguousarray(rD, np.float32)
+        t = np.array(t, np.float32, copy=True).reshape(-1, 64)
+        n = t.shape[0]
+        tri = np.zeros((n, 64), np.int32)
+        u = np.zeros((n, 64), np.float32)
+        v = np.zeros((n, 64), np.float32)
+        self.L.ora_trace_packets(self.h, n, _p(O), _p(D), _p(rD), _p(t), _p(tri), _p(u), _p(v))
+        return t, tri, u, v
+
+    def trace_rays(self, O, D, t):
+        O = np.ascontiguousarray(O, np.float32)
+        D = np.ascontiguousarray(D, np.float32)
+        t = np.array(t, np.float32, copy=True).reshape(-1)
+        n = t.shape[0]
+        tri = np.zeros(n, np.int32)
+        u = np.zeros(n, np.float32)
+        v = np.zeros(n, np.float32)
+        self.L.ora_trace_rays(self.h, n, _p(O), _p(D), _p(t), _p(tri), _p(u), _p(v))
+        return t, tri, u, v
 
     def gen_ray(self, cam, W, H, x, y):
         D = np.zeros(3, np.float32)

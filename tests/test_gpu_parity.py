@@ -1,0 +1,229 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the recorded known
+answers.  Bars: primary hit IDs bit-exact; colours within 1/255 per channel on >= 99.9 % of the
+pixels (the packet path has no transcendental arithmetic, so it is held to bit-exact pixels);
+t/u/v of the traversal operators bit-exact.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib
+from conftest import POSES, bits, colour_mismatch_fraction, pose_cam
+from raytracing_amd import MODE_PACKET, MODE_RECURSIVE, Camera, MrtError, Raytracer, binding, scene_io
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt512(maze_scene):
+    rt = Raytracer(512, 512, device=0)
+    rt.build_bvh(maze_scene)
+    yield rt
+    rt.close()
+
+
+def _check_frame(rt, ora, cam, W, H, mode, spp_grid=1, exact_pixels=True):
+    fb, ids = rt.render(cam, mode=mode, spp_grid=spp_grid)
+    ref = ora.render(cam, W, H, mode=mode, spp_grid=spp_grid)
+    assert np.array_equal(ids, ref["ids"]), "hit IDs differ on %d rays" % int((ids != ref["ids"]).sum())
+    frac = colour_mismatch_fraction(fb, ref["fb"])
+    assert frac <= 0.001, "colours beyond 1/255 on %.4f %% of pixels" % (100 * frac)
+    if exact_pixels:
+        assert np.array_equal(fb, ref["fb"]), "%d pixels differ" % int((fb != ref["fb"]).sum())
+    return fb, ids, ref
+
+
+@pytest.mark.parametrize("pose", POSES, ids=[p[0] for p in POSES])
+def test_packet_frames_match_oracle(rt512, maze_oracle, pose):
+    _check_frame(rt512, maze_oracle, pose_cam(pose), 512, 512, MODE_PACKET)
+
+
+@pytest.mark.parametrize("pose", POSES, ids=[p[0] for p in POSES])
+def test_recursive_frames_match_oracle(rt512, maze_oracle, pose):
+    fb, ids, ref = _check_frame(rt512, maze_oracle, pose_cam(pose), 512, 512, MODE_RECURSIVE, exact_pixels=False)
+    counts = rt512.ray_counts()
+    c = maze_oracle.render(pose_cam(pose), 512, 512, mode=MODE_RECURSIVE, want_counters=True)["counters"]
+    assert counts["primary"] == c["primary_rays"] == 512 * 512
+    assert counts["shadow"] == c["shadow_rays"] and counts["secondary"] == c["secondary_rays"]
+    assert counts["primary_hits"] == int((ids >= 0).sum())
+
+
+@pytest.mark.parametrize("i", range(4))
+def test_known_answer_frames_on_gpu(maze_scene, known, i):
+    """The recorded whole-frame answers of the reference, reproduced by the GPU alone (no oracle)."""
+    k = known["packet_frames"][i]
+    rt = Raytracer(k["W"], k["H"], device=0)
+    rt.build_bvh(maze_scene)
+    cam = Camera()
+    if k["pose"] is not None:
+        cam.set_position(k["pose"]["pos"])
+        cam.look_at(k["pose"]["target"])
+    fb, ids = rt.render(cam, mode=MODE_PACKET)
+    counts = rt.ray_counts()
+    rt.close()
+    assert int((ids >= 0).sum()) == k["hits"] == counts["primary_hits"] == counts["shadow"]
+    assert oracle_lib.idsum(ids) == k["idsum"]
+    assert "%016x" % oracle_lib.fbhash(fb) == k["fbhash"]
+
+
+def test_known_answer_rays_on_gpu(maze_scene, known):
+    rt = Raytracer(800, 600, device=0)
+    rt.build_bvh(maze_scene)
+    fb, ids = rt.render(oracle_lib.IDENTITY, mode=MODE_PACKET)
+    rt.close()
+    for k in known["rays_800x600_P0"]:
+        x, y = k["px"]
+        assert int(ids[y, x]) == k["hit"] and "%08x" % fb[y, x] == k["pixel"]
+
+
+def test_full_hd_both_modes_match_oracle(maze_scene, maze_oracle):
+    """The headline configuration's size: 1920x1080, packet and recursive."""
+    rt = Raytracer(1920, 1080, device=0)
+    rt.build_bvh(maze_scene)
+    cam = pose_cam(POSES[1])
+    _check_frame(rt, maze_oracle, cam, 1920, 1080, MODE_PACKET)
+    _check_frame(rt, maze_oracle, cam, 1920, 1080, MODE_RECURSIVE, exact_pixels=False)
+    rt.close()
+
+
+def _random_rays(rng, n, scene_lo, scene_hi):
+    O = rng.uniform(scene_lo, scene_hi, (n, 3)).astype(np.float32)
+    D = rng.normal(size=(n, 3)).astype(np.float32)
+    D /= np.linalg.norm(D, axis=1, keepdims=True).astype(np.float32)
+    # axis-aligned and zero-component directions: 1/D = +-inf and 0*inf = NaN paths
+    D[::17, 0] = 0.0
+    D[::29, 1] = -0.0
+    D[::31] = np.float32([0, -1, 0])
+    D[5::37] = np.float32([0, 0, -1])
+    return O, D.astype(np.float32)
+
+
+def test_trace_packets_operator_bit_exact(rt512, maze_oracle):
+    rng = np.random.RandomState(11)
+    n = 96 * 64
+    O, D = _random_rays(rng, n, (-18, -1, -20), (18, 6, 20))
+    # coherent packets too: a common origin per packet
+    O[: 48 * 64] = np.repeat(O[:48], 64, axis=0)
+    with np.errstate(divide="ignore"):
+        rD = (np.float32(1.0) / D).astype(np.float32)
+    t = np.full(n, 1e8, np.float32)
+    t[::7] = np.float32(rng.uniform(0.5, 10, len(t[::7])))
+    g = rt512.trace_packets(O.reshape(-1, 64, 3), D.reshape(-1, 64, 3), rD.reshape(-1, 64, 3), t)
+    r = maze_oracle.trace_packets(O.reshape(-1, 64, 3), D.reshape(-1, 64, 3), rD.reshape(-1, 64, 3), t)
+    assert np.array_equal(g[1], r[1])
+    assert np.array_equal(bits(g[0]), bits(r[0]))
+    hit = r[1] >= 0
+    assert hit.sum() > 500
+    assert np.array_equal(bits(g[2])[hit], bits(r[2])[hit]) and np.array_equal(bits(g[3])[hit], bits(r[3])[hit])
+
+
+def test_trace_rays_operator_bit_exact(rt512, maze_oracle, maze_scene):
+    rng = np.random.RandomState(12)
+    n = 20000
+    O, D = _random_rays(rng, n, (-18, -1, -20), (18, 6, 20))
+    # rays that start exactly on a surface, like the reference's shadow rays (no epsilon)
+    m = maze_scene["meshes"][0]
+    tri = m["tri"][rng.randint(0, len(m["tri"]), 4000)]
+    w = rng.dirichlet((1, 1, 1), 4000).astype(np.float32)
+    O[:4000] = (m["pos"][tri[:, 0]] * w[:, 0:1] + m["pos"][tri[:, 1]] * w[:, 1:2] + m["pos"][tri[:, 2]] * w[:, 2:3]).astype(np.float32)
+    t = np.full(n, np.inf, np.float32)
+    t[::5] = np.float32(1e8)
+    g = rt512.trace_rays(O, D, t)
+    r = maze_oracle.trace_rays(O, D, t)
+    assert np.array_equal(g[1], r[1])
+    assert np.array_equal(bits(g[0]), bits(r[0]))
+    hit = r[1] >= 0
+    assert hit.sum() > 1000
+    assert np.array_equal(bits(g[2])[hit], bits(r[2])[hit]) and np.array_equal(bits(g[3])[hit], bits(r[3])[hit])
+
+
+@pytest.mark.parametrize("g", [2, 4])
+def test_supersampling_grid_matches_oracle(maze_scene, maze_oracle, g):
+    rt = Raytracer(256, 128, device=0)
+    rt.build_bvh(maze_scene)
+    _check_frame(rt, maze_oracle, pose_cam(POSES[1]), 256, 128, MODE_PACKET, spp_grid=g)
+    rt.close()
+
+
+def _soup_with_materials(n, seed):
+    s = scene_io.soup_scene(n, seed=seed)
+    m = s["meshes"][0]
+    # split into three meshes with different materials so reflection AND refraction both recurse
+    third = (n // 3) * 3
+    parts = []
+    for j, (refl, refr, rindex) in enumerate(((0.0, 0.0, 1.0), (0.4, 0.0, 1.0), (0.2, 0.3, 1.5))):
+        lo, hi = j * third // 3, ((j + 1) * third // 3 if j < 2 else n)
+        v0, v1 = lo * 3, hi * 3
+        parts.append({"pos": m["pos"][v0:v1], "uv": m["uv"][v0:v1], "norm": m["norm"][v0:v1], "N": m["N"][lo:hi],
+                      "tri": (m["tri"][lo:hi] - v0).astype(np.int32), "texture": 0,
+                      "bounds": np.concatenate([m["pos"][v0:v1].min(0), m["pos"][v0:v1].max(0)]),
+                      "refl": refl, "refr": refr, "rindex": rindex})
+    s["meshes"] = parts
+    return s
+
+
+@pytest.mark.parametrize("n,lights", [(3000, 1), (40000, 3), (500, 0)])
+def test_soup_scenes_both_modes(n, lights):
+    scene = _soup_with_materials(n, seed=n)
+    ora = oracle_lib.Oracle()
+    ora.add_scene(scene)
+    ora.build_bvh()
+    ora.set_threads(8)
+    rt = Raytracer(256, 256, device=0)
+    rt.build_bvh(scene)
+    L = np.float32([[0, 5, 0, 1, 1, 1, 1], [10, 3, -20, 0, 0.5, 0.25, 1.0], [-8, -4, -10, 0, 0.2, 0.9, 0.3]])[:lights]
+    ora.set_lights(L)
+    rt.set_lights(L)
+    for pose in (POSES[0], ("soup", (5, 1, 4), (0, 0, -20))):
+        cam = pose_cam(pose)
+        _check_frame(rt, ora, cam, 256, 256, MODE_PACKET)
+        _check_frame(rt, ora, cam, 256, 256, MODE_RECURSIVE, exact_pixels=False)
+    rt.close()
+
+
+def test_tiny_and_empty_scenes():
+    rt = Raytracer(64, 64, device=0)
+    for n in (0, 1, 2, 3):
+        scene = scene_io.soup_scene(max(n, 1), seed=3)
+        if n == 0:
+            scene["meshes"] = []
+        ora = oracle_lib.Oracle()
+        ora.add_scene(scene)
+        ora.build_bvh()
+        rt.build_bvh(scene)
+        for mode in (MODE_PACKET, MODE_RECURSIVE):
+            fb, ids, ref = _check_frame(rt, ora, oracle_lib.IDENTITY, 64, 64, mode)
+            if n == 0:
+                assert (fb == 0xFF4C4C4C).all() and (ids == -1).all()
+    rt.close()
+
+
+def test_row_bands_on_device_equal_full_frame(maze_scene):
+    """mrt_render_device on disjoint tile-row bands (what each GPU of a multi-GPU run does)
+    writes exactly the full frame's pixels."""
+    import torch
+    W, H = 512, 256
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(maze_scene)
+    cam = pose_cam(POSES[2])
+    full, _ = rt.render(cam, mode=MODE_RECURSIVE)
+    fb = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
+    for y0, y1 in ((0, 64), (64, 72), (72, 256)):
+        rt.render_device(cam, fb.data_ptr(), W, mode=MODE_RECURSIVE, rows=(y0, y1), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(fb.cpu().numpy().view(np.uint32), full)
+    rt.close()
+
+
+def test_error_paths(maze_scene):
+    rt = Raytracer(64, 64, device=0)
+    with pytest.raises(MrtError, match="scene_upload"):
+        rt.render(oracle_lib.IDENTITY)
+    rt.build_bvh(maze_scene)
+    with pytest.raises(MrtError, match="grid"):
+        rt.render(oracle_lib.IDENTITY, spp_grid=3)
+    with pytest.raises(MrtError, match="mode"):
+        rt.render(oracle_lib.IDENTITY, mode=7)
+    bad = {"textures": maze_scene["textures"], "meshes": [dict(maze_scene["meshes"][0], texture=9)]}
+    with pytest.raises(MrtError, match="texture"):
+        rt.build_bvh(bad)
+    rt.close()

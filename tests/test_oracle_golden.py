@@ -1,0 +1,165 @@
+"""The CPU oracle against the known answers recorded from the reference (no GPU needed).
+
+These pins are what makes the oracle trustworthy: BVH structure and hashes, four whole-frame
+framebuffer hashes / hit counts / hit-ID checksums, seven single rays with bit patterns, the
+work counters, and the glm arithmetic vectors produced by the reference's vendored glm headers.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from conftest import bits, hexbits
+
+
+def test_scene_fixture_matches_recorded_loader_output(maze_scene, known):
+    for m, k in zip(maze_scene["meshes"], known["scene"]["meshes"]):
+        assert len(m["pos"]) == k["verts"] and len(m["N"]) == k["tris"]
+        np.testing.assert_allclose(m["bounds"], k["bounds"], rtol=0, atol=6e-5)
+        t = maze_scene["textures"][m["texture"]]
+        assert [t["w"], t["h"]] == k["texture_wh"]
+    assert len(maze_scene["meshes"]) == 2
+
+
+@pytest.mark.skipif(not os.path.isdir(oracle_lib.REF_ASSETS), reason="reference assets not present")
+def test_obj_loader_restatement_reproduces_fixture(maze_scene):
+    cwd = os.getcwd()
+    os.chdir(os.path.dirname(oracle_lib.REF_ASSETS))
+    try:
+        o = oracle_lib.Oracle()
+        o.load_obj("assets/maze.obj")
+        s = o.export_scene()
+    finally:
+        os.chdir(cwd)
+    assert len(s["meshes"]) == len(maze_scene["meshes"]) and len(s["textures"]) == len(maze_scene["textures"])
+    for a, b in zip(s["meshes"], maze_scene["meshes"]):
+        for k in ("pos", "uv", "norm", "N", "bounds"):
+            assert np.array_equal(bits(a[k]), bits(b[k])), k
+        assert np.array_equal(a["tri"], b["tri"]) and a["texture"] == b["texture"]
+    for a, b in zip(s["textures"], maze_scene["textures"]):
+        assert (a["w"], a["h"]) == (b["w"], b["h"])
+        assert np.array_equal(a["idx"], b["idx"]) and np.array_equal(a["pal"], b["pal"])
+
+
+def test_bvh_known_answers(maze_oracle, known):
+    k = known["bvh"]
+    info = maze_oracle.bvh_info
+    assert info["nTris"] == k["nTris"] and info["nNodes"] == k["nNodesAlloc"]
+    assert info["poolPtr"] == k["poolPtr"] and info["maxDepth"] == k["maxDepth"]
+    mm, fc, idx = maze_oracle.bvh_arrays()
+    assert list(idx[:8]) == k["idx_head"]
+    assert "%016x" % maze_oracle.idxhash() == k["idxhash"]
+    assert "%016x" % maze_oracle.nodehash() == k["nodehash"]
+    assert fc[0, 0] == k["root_firstLeft"] and fc[3, 0] == k["node3_firstLeft"] and fc[4, 0] == k["node4_firstLeft"]
+    assert fc[0, 1] == 0 and fc[3, 1] == 0 and fc[4, 1] == 0
+    np.testing.assert_array_equal(mm[0], np.float32(k["root_min"] + k["root_max"]))
+    # reachable nodes and leaf-size histogram
+    reach, stack, leaves = 0, [0], []
+    while stack:
+        n = stack.pop()
+        reach += 1
+        if fc[n, 1]:
+            leaves.append(int(fc[n, 1]))
+        else:
+            stack += [int(fc[n, 0]), int(fc[n, 0]) + 1]
+    assert len(leaves) == k["leaves"] and reach - len(leaves) == k["inner"]
+    hist = {}
+    for c in leaves:
+        hist[str(c)] = hist.get(str(c), 0) + 1
+    assert hist == k["leaf_hist"]
+    assert sorted(idx.tolist()) == list(range(k["nTris"]))
+
+
+def test_view_plane_known_answer(known):
+    k = known["view_plane_800x600_P0"]
+    out = np.zeros(11, np.float32)
+    oracle_lib.lib().ora_view_plane(oracle_lib._p(oracle_lib.IDENTITY), 800, 600, oracle_lib._p(out))
+    np.testing.assert_array_equal(out[0:3], np.float32(k["p0"]))
+    np.testing.assert_array_equal(out[3:6], np.float32(k["p1"]))
+    np.testing.assert_array_equal(out[6:9], np.float32(k["p2"]))
+    assert "%08x" % bits(out[9:10])[0] == k["invW_bits"] and "%08x" % bits(out[10:11])[0] == k["invH_bits"]
+
+
+@pytest.mark.parametrize("i", range(4))
+def test_packet_frame_known_answers(maze_oracle, known, i):
+    k = known["packet_frames"][i]
+    cam = oracle_lib.IDENTITY if k["pose"] is None else oracle_lib.lookat(k["pose"]["pos"], k["pose"]["target"])
+    r = maze_oracle.render(cam, k["W"], k["H"], mode=0)
+    assert int((r["ids"] >= 0).sum()) == k["hits"]
+    assert oracle_lib.idsum(r["ids"]) == k["idsum"]
+    assert "%016x" % oracle_lib.fbhash(r["fb"]) == k["fbhash"]
+    miss = r["fb"][r["ids"] < 0]
+    assert (miss == int(known["miss_pixel"], 16)).all()
+    assert ((r["fb"][r["ids"] >= 0] >> 24) == 0).all()     # hit pixels carry alpha 0
+
+
+def test_single_ray_known_answers(maze_oracle, known):
+    r = maze_oracle.render(oracle_lib.IDENTITY, 800, 600, mode=0, want_tuv=True)
+    for k in known["rays_800x600_P0"]:
+        x, y = k["px"]
+        D, rD = maze_oracle.gen_ray(oracle_lib.IDENTITY, 800, 600, x, y)
+        assert hexbits(D) == k["D"], k
+        assert int(r["ids"][y, x]) == k["hit"]
+        assert "%08x" % r["fb"][y, x] == k["pixel"]
+        t, u, v = r["tuv"][y, x]
+        assert hexbits([t])[0] == k["t"]
+        if k["hit"] >= 0:
+            assert hexbits([u])[0] == k["u"] and hexbits([v])[0] == k["v"]
+            # the same ray alone: scalar traversal from the root and brute force agree with the packet
+            for fn in (lambda: maze_oracle.trace_ray((0, 0, 0), D, 1e8, kind=0), lambda: maze_oracle.trace_ray_brute((0, 0, 0), D, 1e8)):
+                tri, tt, uv = fn()
+                assert tri == k["hit"] and hexbits([tt])[0] == k["t"]
+
+
+def test_work_counters_known_answers(maze_oracle, known):
+    k = known["work_800x600_P0"]
+    c = maze_oracle.render(oracle_lib.IDENTITY, 800, 600, mode=0, want_counters=True)["counters"]
+    rays = c["primary_rays"]
+    assert rays == 480000 and c["shadow_rays"] == k["shadow_rays"] == c["scalar_rays"]
+    assert abs(c["packet_box"] / rays - k["primary_box_per_ray"]) < 0.02
+    assert abs(c["packet_tri"] / rays - k["primary_tri_per_ray"]) < 0.01
+    assert abs(c["packet_nodes"] / k["packets"] - k["node_visits_per_packet"]) < 0.05
+    assert abs(c["packet_leaves"] / k["packets"] - k["leaf_visits_per_packet"]) < 0.05
+    assert abs(c["scalar_nodes"] / c["shadow_rays"] - k["shadow_node_visits_per_ray"]) < 0.01
+    assert abs(c["scalar_box"] / c["shadow_rays"] / 2 - k["shadow_inner_per_ray"]) < 0.01
+    assert abs(c["scalar_tri"] / c["shadow_rays"] - k["shadow_tri_per_ray"]) < 0.01
+
+
+def test_glm_vectors_oracle_math(glm_vectors):
+    """ora_math.h against the bit patterns produced by the reference's vendored glm."""
+    L = oracle_lib.lib()
+    for p in glm_vectors["poses"]:
+        cam = oracle_lib.lookat(p["pos"], p["target"])
+        assert hexbits(cam) == p["cam"], p["pos"]
+        inv = np.zeros(16, np.float32)
+        L.ora_mat4_inverse(oracle_lib._p(cam), oracle_lib._p(inv))
+        assert hexbits(inv) == p["inv"]
+        vp = np.zeros(11, np.float32)
+        L.ora_view_plane(oracle_lib._p(cam), p["W"], p["H"], oracle_lib._p(vp))
+        assert hexbits(vp[0:3]) == p["p0"] and hexbits(vp[3:6]) == p["p1"] and hexbits(vp[6:9]) == p["p2"]
+
+
+def test_recursive_mode_differs_from_packet_mode_as_recorded(maze_oracle):
+    """The survey recorded that the recursive shader and the packet path differ on 32.7 % of the
+    512x512 pixels at the default pose (refraction); a coarse pin on the recursive restatement."""
+    a = maze_oracle.render(oracle_lib.IDENTITY, 512, 512, mode=0)["fb"]
+    b = maze_oracle.render(oracle_lib.IDENTITY, 512, 512, mode=1)["fb"]
+    frac = float((a != b).mean())
+    assert abs(frac - 0.327) < 0.002, frac
+
+
+def test_packet_equals_scalar_equals_bruteforce(maze_oracle):
+    """Cross-check recorded by the survey: on the maze, packet result == per-ray traversal from
+    the root == brute force, hit ID and t bits (sampled here)."""
+    cam = oracle_lib.lookat((3, 4, 10), (0, 0, 0))
+    r = maze_oracle.render(cam, 256, 256, mode=0, want_tuv=True)
+    rng = np.random.RandomState(1)
+    for _ in range(300):
+        x, y = int(rng.randint(256)), int(rng.randint(256))
+        D, _ = maze_oracle.gen_ray(cam, 256, 256, x, y)
+        O = cam[12:15]
+        tri, t, uv = maze_oracle.trace_ray(O, D, 1e8, kind=0)
+        tri2, t2, uv2 = maze_oracle.trace_ray_brute(O, D, 1e8)
+        assert tri == tri2 == int(r["ids"][y, x])
+        assert bits([t])[0] == bits([t2])[0] == bits(r["tuv"][y, x, 0:1])[0]
