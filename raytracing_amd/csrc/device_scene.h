@@ -5,12 +5,12 @@
 //             [2i]   = {min.x, min.y, min.z, bits(firstLeft)}
 //             [2i+1] = {max.x, max.y, max.z, bits(count)}
 //           An inner node's two children are slots firstLeft and firstLeft+1, i.e. 64
-//           contiguous bytes.  For a leaf, firstLeft is the first record in `ltri`.
-//   ltri  : 3 x float4 per LEAF-ORDER slot k (position in BVH::m_TriangleIdx), so a leaf's
-//           triangles are contiguous and are read front to back like the reference does:
-//             [3k]   = {p0.x, p0.y, p0.z, bits(triangle id)}
-//             [3k+1] = {e1 = p1-p0, 0}      (the subtraction Triangle::Intersect performs first)
-//             [3k+2] = {e2 = p2-p0, 0}
+//           contiguous bytes.  For a leaf, firstLeft is the first record in the triangle arrays.
+//   triA/triB/triC : 40 bytes per LEAF-ORDER slot k (position in BVH::m_TriangleIdx), so a
+//           leaf's triangles are contiguous and are read front to back like the reference does:
+//             triA[k] = {p0.x, p0.y, p0.z, e1.x}       e1 = p1-p0, e2 = p2-p0: the two
+//             triB[k] = {e1.y, e1.z, e2.x, e2.y}       subtractions Triangle::Intersect
+//             triC[k] = {e2.z, bits(triangle id)}      performs first (raytracer.cpp:289-290)
 //   attr  : 4 x float4 per triangle ID (shading only, touched once per hit):
 //             [4t]   = {normal.xyz, refl}
 //             [4t+1] = {uv0.x, uv0.y, uv1.x, uv1.y}
@@ -19,7 +19,10 @@
 //   tex   : int4 per texture {offset of its texels in `texels`, width, height, 0}
 //   texels: all palette-index bytes back to back
 //   pal   : 32 x 256 uint32 per texture (surface.h:53), level 15 is what the tracer reads
-//   lights: 8 floats per light {pos.xyz, pad, colour.xyzw}
+//   lights: 2 float4 per light {pos.xyz, 0}, {colour.xyzw}
+//
+// Small scenes (nodes + triangle arrays up to about 110 KB, e.g. the default maze: 25 KB +
+// 85 KB) are additionally copied into every workgroup's LDS by the resident kernel.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,15 +31,19 @@ namespace mrt {
 
 struct SceneDev {
     const float4* nodes;
-    const float4* ltri;
+    const float4* triA;
+    const float4* triB;
+    const float2* triC;
     const float4* attr;
     const int4* tex;
     const uint8_t* texels;
     const uint32_t* pal;
-    const float4* lights;     // 2 float4 per light
+    const float4* lights;
     int n_lights;
     int n_tris;
     int n_textures;
+    int n_node_slots;     // node slots in use (poolPtr + 1)
+    int coords_ok;        // every node bound is 0 or 2^-27 <= |c| <= 2^30: exact-division shortcut allowed
 };
 
 struct FrameDev {
@@ -48,11 +55,16 @@ struct FrameDev {
     int n_tiles;             // tiles in this launch
     int grid_g;              // supersampling grid g: 1, 2, 4 or 8
     int pitch;               // output row pitch in pixels
+    int stack_entries;       // per-ray traversal stack entries this BVH needs (depth + 2)
     uint32_t* fb;            // output frame (output resolution)
     int32_t* hit_ids;        // optional, traced-image resolution
-    unsigned long long* counters;   // [0] primary rays [1] shadow rays [2] secondary rays [3] primary hits
+    // [0] primary rays [1] shadow rays [2] secondary rays [3] primary hits [4] next tile (work counter)
+    unsigned long long* counters;
 };
 
-constexpr int kStackDepth = 64;   // per-ray traversal stack entries; BVH depth must stay below
+constexpr int kCounterSlots = 8;
+constexpr int kStackDepth = 64;        // per-ray traversal stack entries; BVH depth must stay below
+constexpr int kResidentThreads = 1024; // workgroup size of the LDS-resident kernel (16 waves)
+constexpr int kLdsBudget = 160 * 1024; // bytes of LDS per CU on gfx950
 
 }  // namespace mrt

@@ -2,14 +2,24 @@
 //
 // Mapping: one wavefront = one 8x8 pixel tile = one 64-ray packet of the reference
 // (raytracer.h:6 PACKETSIZE, game.h:6 TILESIZE); lane k is ray k of the packet, i.e. pixel
-// (tile.x + k%8, tile.y + k/8) exactly as threads.cpp:196-211 numbers them.  The packet
-// traversal keeps the reference's "first active ray" semantics with wave-uniform control
-// flow (ballot + find-first-set); shadow and secondary rays use an independent per-lane
-// traversal with a per-lane stack in LDS.
+// (tile.x + k%8, tile.y + k/8) exactly as threads.cpp:196-211 numbers them.
+//
+// Three traversals, all bit-faithful to the reference's results:
+//   traverse_packet   64-ray "first active ray" packet traversal (primary rays of Render),
+//                     wave-uniform control flow, node/triangle data fetched once per wave;
+//   traverse_nearest  independent per-lane nearest-hit traversal (every ray of the recursive
+//                     shader), per-lane stack in LDS, inner-node and leaf phases kept apart;
+//   occluded_wave     shadow rays of one wave traced together: the reference only uses
+//                     "was anything hit", which does not depend on visiting order, so the 64
+//                     rays share one work list and each lane keeps its own activity bit.
+// Scene data comes either from global memory (any size; wave-uniform reads become scalar
+// loads) or from an LDS copy held by a persistent 16-wave workgroup (small scenes).
 //
 // All arithmetic that decides a hit or a colour follows the reference's operation order;
 // this file must be compiled with -ffp-contract=off and without fast-math.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 
 #include "device_scene.h"
 #include "mrt_math.h"
@@ -18,13 +28,57 @@ namespace mrt {
 
 #define MRT_BACKGROUND f4{1.0f, 0.3f, 0.3f, 0.3f}   // raytracer.cpp:5
 #define MRT_AMBIENT    f4{1.0f, 0.0f, 0.0f, 0.0f}   // raytracer.cpp:6
+#define MRT_LDS __attribute__((address_space(3)))
 constexpr float kEpsilon = 1e-4f;                   // raytracer.cpp:7
 constexpr int kMaxReflPasses = 5, kMaxRefrPasses = 5;   // raytracer.cpp:9-10
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 struct Hit { int tri; float u, v; };
 
+// Loop budget shared by every traversal loop of one tile.  No correct traversal comes near it
+// (it is sized from the node and triangle counts); if a loop ever exhausts it, the loop ends,
+// a code is left in counters[5] for the host to report, and the kernel still terminates.
+struct Watch {
+    int left;
+    unsigned long long* flag;
+    __device__ __forceinline__ bool expired(unsigned long long code) {
+        if (--left >= 0) return false;
+        if (flag) atomicOr(flag, code);
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// Scene accessors: the traversals are written once and instantiated for both homes of the
+// node / triangle arrays.  Indices are in units of the array element.
+// ---------------------------------------------------------------------------------------
+struct SceneGlobal {
+    const v4f* nodes; const v4f* triA; const v4f* triB; const v2f* triC;
+    __device__ __forceinline__ v4f node(uint32_t i) const { return nodes[i]; }
+    __device__ __forceinline__ v4f tri_a(uint32_t k) const { return triA[k]; }
+    __device__ __forceinline__ v4f tri_b(uint32_t k) const { return triB[k]; }
+    __device__ __forceinline__ v2f tri_c(uint32_t k) const { return triC[k]; }
+    __device__ __forceinline__ uint32_t node_first(uint32_t n) const { return __float_as_uint(reinterpret_cast<const float*>(nodes)[8 * n + 3]); }
+    __device__ __forceinline__ uint32_t node_count(uint32_t n) const { return __float_as_uint(reinterpret_cast<const float*>(nodes)[8 * n + 7]); }
+};
+struct SceneLds {
+    MRT_LDS const v4f* nodes; MRT_LDS const v4f* triA; MRT_LDS const v4f* triB; MRT_LDS const v2f* triC;
+    __device__ __forceinline__ v4f node(uint32_t i) const { return nodes[i]; }
+    __device__ __forceinline__ v4f tri_a(uint32_t k) const { return triA[k]; }
+    __device__ __forceinline__ v4f tri_b(uint32_t k) const { return triB[k]; }
+    __device__ __forceinline__ v2f tri_c(uint32_t k) const { return triC[k]; }
+    __device__ __forceinline__ uint32_t node_first(uint32_t n) const { return __float_as_uint(((MRT_LDS const float*)nodes)[8 * n + 3]); }
+    __device__ __forceinline__ uint32_t node_count(uint32_t n) const { return __float_as_uint(((MRT_LDS const float*)nodes)[8 * n + 7]); }
+};
+
+__device__ __forceinline__ f3 xyz(v4f v) { return {v.x, v.y, v.z}; }
 __device__ __forceinline__ f3 xyz(float4 v) { return {v.x, v.y, v.z}; }
-__device__ __forceinline__ uint32_t wbits(float4 v) { return __float_as_uint(v.w); }
+__device__ __forceinline__ uint32_t wbits(v4f v) { return __float_as_uint(v.w); }
+__device__ __forceinline__ float lane_bcast(float x, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
 
 // ---------------------------------------------------------------------------------------
 // Ray/box: the predicate of raytracer.cpp:876-883 (CheckBox), :1227-1237 and :1389-1393.
@@ -36,6 +90,12 @@ __device__ __forceinline__ void slab_terms(f3 tMin, f3 tMax, float& tNear, float
     tNear = gmax(gmax(t1.x, t1.y), t1.z);
     tFar = gmin(gmin(t2.x, t2.y), t2.z);
 }
+// Same terms when no operand can be a NaN: hardware min/max then agree with compare+select
+// except for the sign of a zero, which none of the predicates below can see.
+__device__ __forceinline__ void slab_terms_finite(f3 tMin, f3 tMax, float& tNear, float& tFar) {
+    tNear = fmaxf(fmaxf(fminf(tMin.x, tMax.x), fminf(tMin.y, tMax.y)), fminf(tMin.z, tMax.z));
+    tFar = fminf(fminf(fmaxf(tMin.x, tMax.x), fmaxf(tMin.y, tMax.y)), fmaxf(tMin.z, tMax.z));
+}
 __device__ __forceinline__ bool slab_pass(float tNear, float tFar, float t) {
     return (tFar >= tNear) && (tNear < t) && (tFar > 0);
 }
@@ -45,133 +105,271 @@ __device__ __forceinline__ bool slab_mul(f3 bmin, f3 bmax, f3 O, f3 rD, float t,
     slab_terms((bmin - O) * rD, (bmax - O) * rD, tNear, tFar);
     return slab_pass(tNear, tFar, t);
 }
-// true division by D: scalar path children (raytracer.cpp:1227, 1233)
-__device__ __forceinline__ bool slab_div(f3 bmin, f3 bmax, f3 O, f3 D, float t, float& tNear) {
-    float tFar;
-    slab_terms((bmin - O) / D, (bmax - O) / D, tNear, tFar);
-    return slab_pass(tNear, tFar, t);
+
+// Per-ray constants of the single-ray traversal, whose child tests divide by D
+// (raytracer.cpp:1227, 1233).  r = 1/D lets the twelve divisions of an inner node be replaced
+// by div_by_recip (mrt_math.h) when `shortcut` holds; otherwise true divisions are issued.
+struct RayDiv {
+    f3 O, D, r;
+    bool shortcut;
+};
+__device__ __forceinline__ RayDiv make_ray_div(f3 O, f3 D, bool coords_ok) {
+    RayDiv R;
+    R.O = O; R.D = D;
+    R.r = 1.0f / D;
+    R.shortcut = coords_ok && div_shortcut_dir_ok(D.x) && div_shortcut_dir_ok(D.y) && div_shortcut_dir_ok(D.z) &&
+                 div_shortcut_coord_ok(O.x) && div_shortcut_coord_ok(O.y) && div_shortcut_coord_ok(O.z);
+    return R;
+}
+__device__ __forceinline__ f3 div3(f3 a, const RayDiv& R) {
+    return {div_by_recip(a.x, R.D.x, R.r.x), div_by_recip(a.y, R.D.y, R.r.y), div_by_recip(a.z, R.D.z, R.r.z)};
+}
+// Both children of an inner node.  `shortcut` must be uniform over the lanes that call this.
+__device__ __forceinline__ void slab_div_pair(v4f l0, v4f l1, v4f r0, v4f r1, const RayDiv& R, bool shortcut, float t,
+                                              bool& leftN, bool& rightN, float& tNear, float& tNear2) {
+    float tFar, tFar2;
+    if (shortcut) {
+        slab_terms_finite(div3(xyz(l0) - R.O, R), div3(xyz(l1) - R.O, R), tNear, tFar);
+        slab_terms_finite(div3(xyz(r0) - R.O, R), div3(xyz(r1) - R.O, R), tNear2, tFar2);
+    } else {
+        slab_terms((xyz(l0) - R.O) / R.D, (xyz(l1) - R.O) / R.D, tNear, tFar);
+        slab_terms((xyz(r0) - R.O) / R.D, (xyz(r1) - R.O) / R.D, tNear2, tFar2);
+    }
+    leftN = slab_pass(tNear, tFar, t);
+    rightN = slab_pass(tNear2, tFar2, t);
 }
 
 // ---------------------------------------------------------------------------------------
-// Ray/triangle: Triangle::Intersect / Intersect2 (raytracer.cpp:287-356).  e1 = p1-p0 and
-// e2 = p2-p0 are the reference's first two subtractions, precomputed at upload.
+// Ray/triangle: Triangle::Intersect / Intersect2 (raytracer.cpp:287-356).
+// WAVE_REJECT: the lanes calling this test the SAME triangle (packet leaves, shared shadow
+// traversal).  The exact test needs a correctly rounded 1/det; a hardware reciprocal
+// estimate is enough to see that a ray misses by a clear margin, and the exact division is
+// issued only when some lane cannot be ruled out that way.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void tri_test(f3 p0, f3 e1, f3 e2, int id, f3 O, f3 D, float& t, Hit& h) {
+template <bool WAVE_REJECT>
+__device__ __forceinline__ void tri_test(v4f A, v4f B, v2f C, f3 O, f3 D, float& t, Hit& h) {
+    const f3 p0 = {A.x, A.y, A.z}, e1 = {A.w, B.x, B.y}, e2 = {B.z, B.w, C.x};
     const f3 pvec = cross(D, e2);
     const float det = dot(e1, pvec);
+    const f3 tvec = O - p0;
+    const float un = dot(tvec, pvec);
+    const f3 qvec = cross(tvec, e1);
+    const float vn = dot(D, qvec);
+    const float tn = dot(e2, qvec);
+    if (WAVE_REJECT) {
+        constexpr float m = 1e-5f;      // far above the 2^-22 relative error of estimate * numerator
+        const float rc = __builtin_amdgcn_rcpf(det);
+        const float ua = un * rc, va = vn * rc, ta = tn * rc;
+        bool clear_miss = (det < -kEpsilon) || (ua < -m) || (ua > 1.0f + m) || (va < -m) || (ua + va > 1.0f + 2.0f * m) ||
+                          (ta < -m) || (ta > t * (1.0f + m));
+        clear_miss = clear_miss && (fabsf(det) >= 1e-30f);   // tiny determinants: always decide exactly
+        if (!__any(!clear_miss)) return;
+    }
     if (det < -kEpsilon) return;
     const float invDet = 1 / det;
-    const f3 tvec = O - p0;
-    const float u = dot(tvec, pvec) * invDet;
+    const float u = un * invDet;
     if (u < 0 || u > 1) return;
-    const f3 qvec = cross(tvec, e1);
-    const float v = dot(D, qvec) * invDet;
+    const float v = vn * invDet;
     if (v < 0 || u + v > 1) return;
-    const float T = dot(e2, qvec) * invDet;
+    const float T = tn * invDet;
     if (T < 0.0f) return;
-    if (T < t) { t = T; h.tri = id; h.u = u; h.v = v; }
+    if (T < t) { t = T; h.tri = (int)__float_as_uint(C.y); h.u = u; h.v = v; }
 }
+
+// ---------------------------------------------------------------------------------------
+// A small wave-uniform stack kept in VGPR lanes: entry j is lane j of each register.
+// ---------------------------------------------------------------------------------------
+struct LaneStack1 {
+    uint32_t a = 0;
+    int sp = 0;
+    __device__ __forceinline__ void push(int lane, uint32_t x) { a = (lane == sp) ? x : a; ++sp; }
+    __device__ __forceinline__ uint32_t pop() { --sp; return (uint32_t)__builtin_amdgcn_readlane((int)a, sp); }
+};
+struct LaneStack3 {
+    uint32_t a = 0, b = 0, c = 0;
+    int sp = 0;
+    __device__ __forceinline__ void push(int lane, uint32_t x, unsigned long long m) {
+        const bool me = lane == sp;
+        a = me ? x : a; b = me ? (uint32_t)m : b; c = me ? (uint32_t)(m >> 32) : c;
+        ++sp;
+    }
+    __device__ __forceinline__ void pop(uint32_t& x, unsigned long long& m) {
+        --sp;
+        x = (uint32_t)__builtin_amdgcn_readlane((int)a, sp);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)b, sp), hi = (uint32_t)__builtin_amdgcn_readlane((int)c, sp);
+        m = ((unsigned long long)hi << 32) | lo;
+    }
+};
 
 // ---------------------------------------------------------------------------------------
 // 64-ray packet traversal: BVH::TraverseRayPacket, BVHNode::TraversePacket and
-// IntersectPrimitivesPacket (raytracer.cpp:1349-1464).
+// IntersectPrimitivesPacket (raytracer.cpp:1349-1464).  Must be called by all 64 lanes.
 //
-// The reference recursion "visit(node, firstActive)" becomes a wave-uniform work list of
-// (child, f) scan tasks: pop a task, find the first lane i >= f whose ray passes the child's
-// box with its CURRENT t, and visit the child with firstActive = i.  Visiting an inner node
-// orders its children by lane i's entry distance and pushes two scan tasks (far one first, so
-// the near one is scanned next and the far one only after the near subtree has updated t).
-// Visiting a leaf tests every lane >= i against every triangle of the leaf, in leaf order.
-// The work list lives in one VGPR: entry j is lane j of `stk` (select-write / v_readlane).
+// The reference recursion visit(node, firstActive) is unrolled into a descent plus a work
+// list of deferred "scan" tasks (child, f): find the first lane i >= f whose ray passes the
+// child's box with its CURRENT t, then visit the child with firstActive = i.  Visiting an
+// inner node loads both children once, orders them by lane i's entry distance, defers the
+// far child (it must be re-tested after the near subtree has shortened t) and scans the near
+// child at once from the terms already computed.  Visiting a leaf tests every lane >= i
+// against every triangle of the leaf, in leaf order.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void traverse_packet(const SceneDev& S, f3 O, f3 D, f3 rD, float& t, Hit& h, int lane) {
-    if (S.n_tris == 0) return;
-    uint32_t stk = 0;
-    int sp = 0;
-    auto push = [&](uint32_t node, int f) {
-        stk = (lane == sp) ? ((node << 6) | (uint32_t)f) : stk;
-        ++sp;
-    };
-    push(0u, 0);
-    while (sp > 0) {
-        --sp;
-        const uint32_t e = __builtin_amdgcn_readlane(stk, sp);
-        const uint32_t c = e >> 6;
+template <class SC>
+__device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, f3 D, f3 rD, float& t, Hit& h, int lane, Watch& wd) {
+    if (n_tris == 0) return;
+    LaneStack1 work;
+    work.push(lane, 0u);                       // scan(root, f = 0): raytracer.cpp:1351-1357
+    while (work.sp > 0) {
+        if (wd.expired(1)) break;
+        const uint32_t e = work.pop();
+        uint32_t node = e >> 6;
         const int f = (int)(e & 63u);
-        const float4 n0 = S.nodes[2 * c], n1 = S.nodes[2 * c + 1];
+        const v4f n0 = sc.node(2 * node), n1 = sc.node(2 * node + 1);
         float tn;
         const bool pass = slab_mul(xyz(n0), xyz(n1), O, rD, t, tn);
-        const unsigned long long mask = __ballot(pass) & (~0ull << f);
+        unsigned long long mask = __ballot(pass) & (~0ull << f);
         if (mask == 0) continue;
-        const int i = __ffsll((long long)mask) - 1;
-        const uint32_t first = wbits(n0), count = wbits(n1);
-        if (count != 0) {
-            if (lane >= i) {
-                for (uint32_t k = first; k < first + count; ++k) {
-                    const float4 a = S.ltri[3 * k], b = S.ltri[3 * k + 1], cc = S.ltri[3 * k + 2];
-                    tri_test(xyz(a), xyz(b), xyz(cc), (int)wbits(a), O, D, t, h);
+        int i = __ffsll((long long)mask) - 1;
+        uint32_t first = wbits(n0), count = wbits(n1);
+        for (;;) {                             // visit(node = {first,count}, firstActive = i)
+            if (wd.expired(2)) break;
+            if (count != 0) {
+                if (lane >= i) {
+                    for (uint32_t k = first; k < first + count; ++k) {
+                        if (wd.expired(64)) break;
+                        tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h);
+                    }
                 }
+                break;
             }
-        } else {
             const uint32_t L = first, R = first + 1;
-            const float4 l0 = S.nodes[2 * L], l1 = S.nodes[2 * L + 1];
-            const float4 r0 = S.nodes[2 * R], r1 = S.nodes[2 * R + 1];
-            float tl, tr, unused;
-            slab_terms((xyz(l0) - O) * rD, (xyz(l1) - O) * rD, tl, unused);
-            slab_terms((xyz(r0) - O) * rD, (xyz(r1) - O) * rD, tr, unused);
-            const float tNear = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tl), i));
-            const float tNear2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tr), i));
-            if (tNear2 < tNear) { push(L, i); push(R, i); }   // right is scanned first
-            else                { push(R, i); push(L, i); }
+            const v4f l0 = sc.node(2 * L), l1 = sc.node(2 * L + 1), r0 = sc.node(2 * R), r1 = sc.node(2 * R + 1);
+            float tnl, tfl, tnr, tfr;
+            slab_terms((xyz(l0) - O) * rD, (xyz(l1) - O) * rD, tnl, tfl);
+            slab_terms((xyz(r0) - O) * rD, (xyz(r1) - O) * rD, tnr, tfr);
+            const bool right_first = lane_bcast(tnr, i) < lane_bcast(tnl, i);   // raytracer.cpp:1384
+            work.push(lane, ((right_first ? L : R) << 6) | (uint32_t)i);
+            const bool p = right_first ? slab_pass(tnr, tfr, t) : slab_pass(tnl, tfl, t);
+            mask = __ballot(p) & (~0ull << i);
+            if (mask == 0) break;
+            i = __ffsll((long long)mask) - 1;
+            first = right_first ? wbits(r0) : wbits(l0);
+            count = right_first ? wbits(r1) : wbits(l1);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// Single-ray traversal: BVH::Traverse + BVHNode::Traverse + IntersectPrimitives
+// Single-ray nearest-hit traversal: BVH::Traverse + BVHNode::Traverse + IntersectPrimitives
 // (raytracer.cpp:945-950, 1204-1264, 1328-1346).  Returns true when a hit was recorded.
-// `stack` points at this lane's column of an LDS array laid out [entry][64 lanes].
+// `stack` points at this lane's column of an LDS array laid out [entry][64 lanes].  Lanes
+// first walk inner nodes until each holds a leaf, then all leaves are processed together.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ bool traverse_scalar(const SceneDev& S, f3 O, f3 D, float& t, Hit& h, uint32_t* stack) {
+template <class SC, typename STP>
+__device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool coords_ok, f3 O, f3 D, float& t, Hit& h, STP stack, Watch& wd) {
     h.tri = -1;
-    if (S.n_tris == 0) return false;
+    if (n_tris == 0) return false;
+    const v4f root0 = sc.node(0), root1 = sc.node(1);
     {
         // root gate: the reference hands CheckBox the direction where it expects the reciprocal
-        const float4 r0 = S.nodes[0], r1 = S.nodes[1];
         float tn;
-        if (!slab_mul(xyz(r0), xyz(r1), O, D, t, tn)) return false;
+        if (!slab_mul(xyz(root0), xyz(root1), O, D, t, tn)) return false;
     }
+    const RayDiv R = make_ray_div(O, D, coords_ok);
+    const bool shortcut = __all(R.shortcut);
     int sp = 0;
-    uint32_t node = 0;
-    for (;;) {
-        const float4 n0 = S.nodes[2 * node], n1 = S.nodes[2 * node + 1];
-        const uint32_t first = wbits(n0), count = wbits(n1);
-        bool descend = false;
-        if (count != 0) {
-            for (uint32_t k = first; k < first + count; ++k) {
-                const float4 a = S.ltri[3 * k], b = S.ltri[3 * k + 1], c = S.ltri[3 * k + 2];
-                tri_test(xyz(a), xyz(b), xyz(c), (int)wbits(a), O, D, t, h);
-            }
-        } else {
-            const uint32_t L = first, R = first + 1;
-            const float4 l0 = S.nodes[2 * L], l1 = S.nodes[2 * L + 1];
-            const float4 r0 = S.nodes[2 * R], r1 = S.nodes[2 * R + 1];
+    uint32_t first = wbits(root0), count = wbits(root1);
+    bool alive = true;
+    while (alive) {
+        if (wd.expired(4)) break;
+        while (alive && count == 0) {
+            if (wd.expired(8)) { alive = false; break; }
+            const uint32_t L = first, Rr = first + 1;
+            const v4f l0 = sc.node(2 * L), l1 = sc.node(2 * L + 1), r0 = sc.node(2 * Rr), r1 = sc.node(2 * Rr + 1);
+            bool leftN, rightN;
             float tNear, tNear2;
-            const bool leftN = slab_div(xyz(l0), xyz(l1), O, D, t, tNear);
-            const bool rightN = slab_div(xyz(r0), xyz(r1), O, D, t, tNear2);
+            slab_div_pair(l0, l1, r0, r1, R, shortcut, t, leftN, rightN, tNear, tNear2);
             if (leftN && rightN) {
-                const bool rightFirst = tNear2 < tNear;
-                stack[sp * 64] = rightFirst ? L : R;
+                const bool right_first = tNear2 < tNear;          // raytracer.cpp:1243
+                stack[sp * 64] = right_first ? L : Rr;
                 ++sp;
-                node = rightFirst ? R : L;
-                descend = true;
-            } else if (leftN) { node = L; descend = true; }
-            else if (rightN) { node = R; descend = true; }
+                first = right_first ? wbits(r0) : wbits(l0);
+                count = right_first ? wbits(r1) : wbits(l1);
+            } else if (leftN) { first = wbits(l0); count = wbits(l1); }
+            else if (rightN) { first = wbits(r0); count = wbits(r1); }
+            else if (sp == 0) alive = false;
+            else {
+                --sp;
+                const uint32_t n = stack[sp * 64];
+                first = sc.node_first(n); count = sc.node_count(n);
+            }
         }
-        if (!descend) {
-            if (sp == 0) break;
-            --sp;
-            node = stack[sp * 64];
+        if (alive) {
+            for (uint32_t k = first; k < first + count; ++k) {
+                if (wd.expired(128)) break;
+                tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h);
+            }
+            if (sp == 0) alive = false;
+            else {
+                --sp;
+                const uint32_t n = stack[sp * 64];
+                first = sc.node_first(n); count = sc.node_count(n);
+            }
+        }
+    }
+    return h.tri >= 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Shadow rays of one wave.  Raytracer::IsOccluded (raytracer.cpp:414-418) runs the nearest-hit
+// traversal with t = INFINITY and only asks whether anything was hit.  While nothing has been
+// hit t stays infinite, so the set of leaves the reference reaches is "every leaf whose
+// ancestors' boxes the ray passes with t = INFINITY", whatever the visiting order; and as soon
+// as one triangle of that set is hit the answer is fixed.  So: one shared work list of
+// (node, 64-bit lane mask) entries; a lane belongs to an entry's mask iff its own ray passed
+// every box test on the way (root gate included), and only those lanes test the leaf.
+// Must be called by all 64 lanes; `take_part` selects the lanes that really have a ray.
+// ---------------------------------------------------------------------------------------
+template <class SC>
+__device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coords_ok, f3 O, f3 D, bool take_part, int lane, Watch& wd) {
+    if (n_tris == 0) return false;
+    const v4f root0 = sc.node(0), root1 = sc.node(1);
+    float tn;
+    const bool gate = take_part && slab_mul(xyz(root0), xyz(root1), O, D, INFINITY, tn);   // D, not 1/D (raytracer.cpp:947)
+    unsigned long long m = __ballot(gate);
+    if (m == 0) return false;
+    const RayDiv R = make_ray_div(O, D, coords_ok);
+    const bool shortcut = !__any(take_part && !R.shortcut);
+    float t = INFINITY;
+    Hit h;
+    h.tri = -1;
+    LaneStack3 work;
+    work.push(lane, 0u, m);
+    unsigned long long found = 0;
+    while (work.sp > 0) {
+        if (wd.expired(16)) break;
+        uint32_t node;
+        work.pop(node, m);
+        m &= ~found;
+        if (m == 0) continue;
+        const uint32_t first = sc.node_first(node), count = sc.node_count(node);
+        if (count != 0) {
+            if ((m >> lane) & 1ull) {
+                for (uint32_t k = first; k < first + count; ++k) {
+                    if (wd.expired(256)) break;
+                    if (h.tri < 0) tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h);
+                    if (!__any(h.tri < 0)) break;
+                }
+            }
+            found = __ballot(h.tri >= 0);
+        } else {
+            const uint32_t L = first, Rr = first + 1;
+            const v4f l0 = sc.node(2 * L), l1 = sc.node(2 * L + 1), r0 = sc.node(2 * Rr), r1 = sc.node(2 * Rr + 1);
+            bool leftN, rightN;
+            float a, b;
+            slab_div_pair(l0, l1, r0, r1, R, shortcut, INFINITY, leftN, rightN, a, b);
+            const unsigned long long ml = __ballot(leftN) & m, mr = __ballot(rightN) & m;
+            if (mr) work.push(lane, Rr, mr);
+            if (ml) work.push(lane, L, ml);
         }
     }
     return h.tri >= 0;
@@ -223,20 +421,22 @@ __device__ __forceinline__ Surf fetch_surface(const SceneDev& S, const Hit& h) {
     return s;
 }
 
-// Direct light of raytracer.cpp:551-570 / 604-623: one shadow ray per light, starting exactly
-// on the surface, traced to its nearest hit and used as "anything hit = occluded".
-__device__ __forceinline__ void direct_light(const SceneDev& S, const Surf& s, f3 hit, f4& finalColor,
-                                             uint32_t* stack, uint32_t& n_shadow) {
-    const float lightStrength = 1.0f - (s.refr + s.refl);
-    if (lightStrength > 0.0f) {
-        finalColor = finalColor + (MRT_AMBIENT * s.colorP) * lightStrength;
-        for (int i = 0; i < S.n_lights; ++i) {
-            const float4 lp = S.lights[2 * i], lc = S.lights[2 * i + 1];
-            const f3 L = normalize(xyz(lp) - hit);
-            float lt = INFINITY;
-            Hit sh;
+// Direct light of raytracer.cpp:551-570 / 604-623 for the lanes with `shade` set: one shadow
+// ray per light, starting exactly on the surface (no epsilon).  Must be called by all 64 lanes.
+template <class SC>
+__device__ __forceinline__ void direct_light(const SC& sc, const SceneDev& S, bool shade, const Surf& s, f3 hit, f4& finalColor,
+                                             int lane, uint32_t& n_shadow, Watch& wd) {
+    const float lightStrength = shade ? 1.0f - (s.refr + s.refl) : 0.0f;
+    const bool lit = shade && lightStrength > 0.0f;
+    if (lit) finalColor = finalColor + (MRT_AMBIENT * s.colorP) * lightStrength;
+    if (!__any(lit)) return;
+    for (int i = 0; i < S.n_lights; ++i) {
+        const float4 lp = S.lights[2 * i], lc = S.lights[2 * i + 1];
+        const f3 L = lit ? normalize(xyz(lp) - hit) : f3{0.0f, 0.0f, 1.0f};
+        const bool occluded = occluded_wave(sc, S.n_tris, S.coords_ok != 0, hit, L, lit, lane, wd);
+        if (lit) {
             ++n_shadow;
-            if (!traverse_scalar(S, hit, L, lt, sh, stack)) {
+            if (!occluded) {
                 float d = dot(s.normal, L);
                 if (d < 0.0f) d = 0.0f;
                 finalColor = finalColor + ((d * f4{lc.x, lc.y, lc.z, lc.w}) * s.colorP) * lightStrength;
@@ -253,87 +453,116 @@ __device__ __forceinline__ f3 reflect(f3 I, f3 N) {
     return tan - projN;
 }
 
-// Raytracer::GetColorFromSphere (raytracer.cpp:575-664) without recursion: an explicit frame
-// stack replays "shade, then maybe reflect, then maybe refract, then clamp".  The two pass
-// counters are shared by the whole tree of one pixel (the reference passes them by reference),
-// so they are a budget of 5 + 5 secondary rays, which also bounds the frame stack.
-struct ShadeFrame {
+// Raytracer::GetColorFromSphere (raytracer.cpp:575-664) for the 64 pixels of a tile, without
+// recursion.  Every round, the lanes that hold a ray trace it (per-lane nearest hit), the wave
+// then shades those hits together (shared shadow traversal), and each lane advances its own
+// continuation: "maybe reflect, then maybe refract, then clamp and return to the caller frame".
+// The two pass counters are shared by the whole ray tree of a pixel (the reference passes them
+// by reference), so they are a budget of 5 + 5 secondary rays, which bounds the frame stack.
+// Frames live in private memory; a frame waiting for its refraction ray only needs its colour
+// so far and the Beer's-law factors, one waiting for its reflection ray needs the whole hit.
+constexpr int kFrames = kMaxReflPasses + kMaxRefrPasses + 1;
+constexpr int kFrameWords = 24;
+
+struct ShadeState {
     f4 finalColor, colorP;
     f3 hit, normal, D;
     float t, refl, refr, rindex, curIndex;
-    f3 transparency;
     int stage;      // 0: reflection not tried yet, 1: refraction not tried yet, 2: done
 };
 
-__device__ __forceinline__ f4 shade_recursive(const SceneDev& S, f3 O, f3 D, float tmax, uint32_t* stack,
-                                              Hit& primary, float& primary_t, uint32_t& n_shadow, uint32_t& n_secondary) {
-    ShadeFrame frames[kMaxReflPasses + kMaxRefrPasses + 1];
-    int depth = 0;
-    int reflPass = 0, refrPass = 0;
-    float curIndex = 1.0f;
+template <class SC, typename STP>
+__device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f3 O, f3 D, STP stack, int lane, Hit& primary,
+                                              uint32_t& n_shadow, uint32_t& n_secondary, Watch& wd) {
+    float frames[kFrames][kFrameWords];
+    int depth = 0, reflPass = 0, refrPass = 0;
+    float curIndex = 1.0f, tmax = 100000000;
     f4 ret = MRT_BACKGROUND;
-    ShadeFrame F;
-    bool first = true;
-    enum { CALL, CONT, RET } state = CALL;
-    for (;;) {
-        if (state == CALL) {
-            float t = tmax;
-            Hit h;
-            const bool isHit = traverse_scalar(S, O, D, t, h, stack);
-            if (first) { primary = h; primary_t = t; first = false; }
-            if (!isHit) { ret = MRT_BACKGROUND; state = RET; continue; }
-            const Surf s = fetch_surface(S, h);
-            F.hit = O + D * t;
-            F.normal = s.normal;
-            F.finalColor = {0, 0, 0, 0};
-            F.colorP = s.colorP;
-            F.D = D; F.t = t;
-            F.refl = s.refl; F.refr = s.refr; F.rindex = s.rindex; F.curIndex = curIndex;
-            F.stage = 0;
-            direct_light(S, s, F.hit, F.finalColor, stack, n_shadow);
-            state = CONT;
+    bool tracing = true, first = true;
+    ShadeState F;
+    while (__any(tracing)) {
+        if (wd.expired(32)) break;
+        Hit h;
+        h.tri = -1; h.u = 0; h.v = 0;
+        float t = tmax;
+        bool isHit = false;
+        if (tracing) isHit = traverse_nearest(sc, S.n_tris, S.coords_ok != 0, O, D, t, h, stack, wd);
+        if (tracing && first) { primary = h; first = false; }
+        const bool shade = tracing && isHit;
+        Surf s;
+        s.normal = {0, 0, 1}; s.refl = 0; s.refr = 0; s.rindex = 1; s.colorP = {0, 0, 0, 0};
+        f3 hit = O;
+        if (shade) { s = fetch_surface(S, h); hit = O + D * t; }
+        f4 finalColor = {0, 0, 0, 0};
+        direct_light(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
+        if (!tracing) continue;
+        tracing = false;
+        bool returning;
+        if (!isHit) { ret = MRT_BACKGROUND; returning = true; }
+        else {
+            F.finalColor = finalColor; F.colorP = s.colorP; F.hit = hit; F.normal = s.normal; F.D = D; F.t = t;
+            F.refl = s.refl; F.refr = s.refr; F.rindex = s.rindex; F.curIndex = curIndex; F.stage = 0;
+            returning = false;
         }
-        if (state == CONT) {
-            if (F.stage == 0) {
-                F.stage = 1;
-                if (F.refl > 0.0f && reflPass < kMaxReflPasses) {
-                    reflPass++;
-                    ++n_secondary;
-                    frames[depth++] = F;
-                    O = F.hit; D = reflect(F.D, F.normal); tmax = INFINITY; curIndex = F.curIndex;
-                    state = CALL;
-                    continue;
-                }
-            }
-            if (F.stage == 1) {
-                F.stage = 2;
-                if (F.refr > 0.0f && refrPass < kMaxRefrPasses) {
-                    refrPass++;
-                    const float rindex = F.rindex;
-                    const float n = F.curIndex / rindex;
-                    const float cosI = -dot(F.normal, F.D);
-                    const float cosT2 = 1.0f - n * n * (1.0f - cosI * cosI);
-                    if (cosT2 > 0.0f) {
-                        const f3 T = (n * F.D) + (n * cosI - sqrtf(cosT2)) * F.normal;
-                        const f4 absorbance = (F.colorP * 0.15f) * -F.t;
-                        F.transparency = {expf(absorbance.x), expf(absorbance.y), expf(absorbance.z)};
+        for (;;) {
+            if (!returning) {
+                if (F.stage == 0) {
+                    F.stage = 1;
+                    if (F.refl > 0.0f && reflPass < kMaxReflPasses) {      // raytracer.cpp:625-631
+                        reflPass++;
                         ++n_secondary;
-                        frames[depth++] = F;
-                        O = F.hit + T * kEpsilon; D = T; tmax = INFINITY; curIndex = rindex;
-                        state = CALL;
-                        continue;
+                        float* fr = frames[depth++];
+                        fr[0] = F.finalColor.x; fr[1] = F.finalColor.y; fr[2] = F.finalColor.z; fr[3] = F.finalColor.w;
+                        fr[4] = F.colorP.x; fr[5] = F.colorP.y; fr[6] = F.colorP.z; fr[7] = F.colorP.w;
+                        fr[8] = F.hit.x; fr[9] = F.hit.y; fr[10] = F.hit.z;
+                        fr[11] = F.normal.x; fr[12] = F.normal.y; fr[13] = F.normal.z;
+                        fr[14] = F.D.x; fr[15] = F.D.y; fr[16] = F.D.z;
+                        fr[17] = F.t; fr[18] = F.refl; fr[19] = F.refr; fr[20] = F.rindex; fr[21] = F.curIndex;
+                        fr[23] = 1.0f;
+                        O = F.hit; D = reflect(F.D, F.normal); tmax = INFINITY; curIndex = F.curIndex;
+                        tracing = true;
+                        break;
                     }
                 }
+                if (F.stage == 1) {
+                    F.stage = 2;
+                    if (F.refr > 0.0f && refrPass < kMaxRefrPasses) {      // raytracer.cpp:633-652
+                        refrPass++;
+                        const float rindex = F.rindex;
+                        const float n = F.curIndex / rindex;
+                        const float cosI = -dot(F.normal, F.D);
+                        const float cosT2 = 1.0f - n * n * (1.0f - cosI * cosI);
+                        if (cosT2 > 0.0f) {
+                            const f3 T = (n * F.D) + (n * cosI - sqrtf(cosT2)) * F.normal;
+                            const f4 absorbance = (F.colorP * 0.15f) * -F.t;
+                            ++n_secondary;
+                            float* fr = frames[depth++];
+                            fr[0] = F.finalColor.x; fr[1] = F.finalColor.y; fr[2] = F.finalColor.z; fr[3] = F.finalColor.w;
+                            fr[4] = expf(absorbance.x); fr[5] = expf(absorbance.y); fr[6] = expf(absorbance.z);
+                            fr[23] = 2.0f;
+                            O = F.hit + T * kEpsilon; D = T; tmax = INFINITY; curIndex = rindex;
+                            tracing = true;
+                            break;
+                        }
+                    }
+                }
+                ret = clamp01(F.finalColor);
             }
-            ret = clamp01(F.finalColor);
-            state = RET;
+            if (depth == 0) break;          // the primary ray's colour is in `ret`
+            const float* fr = frames[--depth];
+            F.finalColor = {fr[0], fr[1], fr[2], fr[3]};
+            if (fr[23] == 2.0f) {
+                F.finalColor = F.finalColor + ret * f4{fr[4], fr[5], fr[6], 1.0f};
+                F.stage = 2;
+            } else {
+                F.colorP = {fr[4], fr[5], fr[6], fr[7]};
+                F.hit = {fr[8], fr[9], fr[10]}; F.normal = {fr[11], fr[12], fr[13]}; F.D = {fr[14], fr[15], fr[16]};
+                F.t = fr[17]; F.refl = fr[18]; F.refr = fr[19]; F.rindex = fr[20]; F.curIndex = fr[21];
+                F.finalColor = F.finalColor + (ret * F.colorP) * F.refl;
+                F.stage = 1;
+            }
+            returning = false;
         }
-        // state == RET: hand `ret` to the caller frame, if any
-        if (depth == 0) break;
-        F = frames[--depth];
-        if (F.stage == 1) F.finalColor = F.finalColor + (ret * F.colorP) * F.refl;
-        else F.finalColor = F.finalColor + ret * f4{F.transparency.x, F.transparency.y, F.transparency.z, 1.0f};
-        state = CONT;
     }
     return ret;
 }
@@ -344,19 +573,13 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Frame kernel: ray generation (threads.cpp:189-211), trace, shade, pixel pack + store
-// (threads.cpp:215-224).  MODE 0 = packet path, 1 = recursive shader.  SD = per-lane stack
-// entries.  One 64-thread workgroup (one wave) per 8x8 tile of the traced image.
+// One tile: ray generation (threads.cpp:189-211), trace, shade, pixel pack + store
+// (threads.cpp:215-224).  MODE 0 = packet path, 1 = recursive shader.  All 64 lanes call it.
 // ---------------------------------------------------------------------------------------
-template <int MODE, int SD>
-__global__ __launch_bounds__(64) void render_tiles(SceneDev S, FrameDev F) {
-    __shared__ uint32_t lds_stack[SD * 64];
-    const int lane = threadIdx.x;
-    const int tile = blockIdx.x;
-    if (tile >= F.n_tiles) return;
+template <int MODE, class SC, typename STP>
+__device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, const FrameDev& F, int tile, int lane, STP stack) {
     const int tx = tile % F.tiles_x, ty = F.tile_y0 + tile / F.tiles_x;
     const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
-    uint32_t* stack = lds_stack + lane;
 
     const f3 p0 = {F.p0[0], F.p0[1], F.p0[2]}, d10 = {F.d10[0], F.d10[1], F.d10[2]}, d20 = {F.d20[0], F.d20[1], F.d20[2]};
     const f3 O = {F.cam[0], F.cam[1], F.cam[2]};
@@ -366,24 +589,24 @@ __global__ __launch_bounds__(64) void render_tiles(SceneDev S, FrameDev F) {
     const f3 D = normalize(planepos - O);
 
     uint32_t n_shadow = 0, n_secondary = 0;
+    Watch wd{64 * (4 * S.n_node_slots + S.n_tris + 64), F.counters ? F.counters + 5 : nullptr};
     Hit h;
     h.tri = -1; h.u = 0; h.v = 0;
     f4 color;
     if (MODE == 0) {
         const f3 rD = 1.0f / D;
         float t = 100000000;
-        traverse_packet(S, O, D, rD, t, h, lane);
-        if (h.tri < 0) color = MRT_BACKGROUND;
-        else {
-            const f3 hit = O + D * t;
-            const Surf s = fetch_surface(S, h);
-            f4 finalColor = {0, 0, 0, 0};
-            direct_light(S, s, hit, finalColor, stack, n_shadow);
-            color = clamp01(finalColor);
-        }
+        traverse_packet(sc, S.n_tris, O, D, rD, t, h, lane, wd);
+        const bool shade = h.tri >= 0;
+        Surf s;
+        s.normal = {0, 0, 1}; s.refl = 0; s.refr = 0; s.rindex = 1; s.colorP = {0, 0, 0, 0};
+        f3 hit = O;
+        if (shade) { s = fetch_surface(S, h); hit = O + D * t; }
+        f4 finalColor = {0, 0, 0, 0};
+        direct_light(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
+        color = shade ? clamp01(finalColor) : MRT_BACKGROUND;
     } else {
-        float pt;
-        color = shade_recursive(S, O, D, 100000000, stack, h, pt, n_shadow, n_secondary);
+        color = shade_recursive(sc, S, O, D, stack, lane, h, n_shadow, n_secondary, wd);
     }
     const uint32_t px = vec_to_pixel(color);
 
@@ -417,6 +640,56 @@ __global__ __launch_bounds__(64) void render_tiles(SceneDev S, FrameDev F) {
     }
 }
 
+__device__ __forceinline__ SceneGlobal global_scene(const SceneDev& S) {
+    return SceneGlobal{reinterpret_cast<const v4f*>(S.nodes), reinterpret_cast<const v4f*>(S.triA),
+                       reinterpret_cast<const v4f*>(S.triB), reinterpret_cast<const v2f*>(S.triC)};
+}
+
+// Scene in global memory: one 64-thread workgroup (one wave) per tile.  SD = stack entries.
+template <int MODE, int SD>
+__global__ __launch_bounds__(64) void render_tiles_global(SceneDev S, FrameDev F) {
+    __shared__ uint32_t lds_stack[SD * 64];
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.x;
+    if (tile >= F.n_tiles) return;
+    render_tile<MODE>(global_scene(S), S, F, tile, lane, (MRT_LDS uint32_t*)lds_stack + lane);
+}
+
+// Scene resident in LDS: persistent workgroups of 16 waves copy nodes and triangles into LDS
+// once, then every wave pulls tile numbers from a shared counter until none are left -- the
+// GPU form of the reference's tile queue (threads.cpp:158-169: workers decrement one counter).
+// LDS: nodes | triA | triB | triC | per-lane stacks (16 bit entries: a resident scene has
+// fewer than 65536 node slots).
+template <int MODE>
+__global__ __launch_bounds__(kResidentThreads) void render_tiles_resident(SceneDev S, FrameDev F) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t n_node_v4 = 2u * (uint32_t)S.n_node_slots, n_tri = (uint32_t)S.n_tris;
+    MRT_LDS v4f* l_nodes = (MRT_LDS v4f*)smem;
+    MRT_LDS v4f* l_a = l_nodes + n_node_v4;
+    MRT_LDS v4f* l_b = l_a + n_tri;
+    MRT_LDS v2f* l_c = (MRT_LDS v2f*)(l_b + n_tri);
+    MRT_LDS uint16_t* l_stacks = (MRT_LDS uint16_t*)(l_c + n_tri + (n_tri & 1u));
+    {
+        const v4f* gn = reinterpret_cast<const v4f*>(S.nodes);
+        const v4f* ga = reinterpret_cast<const v4f*>(S.triA);
+        const v4f* gb = reinterpret_cast<const v4f*>(S.triB);
+        const v2f* gc = reinterpret_cast<const v2f*>(S.triC);
+        for (uint32_t i = threadIdx.x; i < n_node_v4; i += blockDim.x) l_nodes[i] = gn[i];
+        for (uint32_t i = threadIdx.x; i < n_tri; i += blockDim.x) { l_a[i] = ga[i]; l_b[i] = gb[i]; l_c[i] = gc[i]; }
+    }
+    __syncthreads();
+    const SceneLds sc{l_nodes, l_a, l_b, l_c};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    MRT_LDS uint16_t* stack = l_stacks + (size_t)wave * F.stack_entries * 64 + lane;
+    for (int pulls = 0; pulls <= F.n_tiles; ++pulls) {      // no wave can draw more tiles than exist
+        unsigned long long next = 0;
+        if (lane == 0) next = atomicAdd(&F.counters[4], 1ull);
+        const int tile = __builtin_amdgcn_readfirstlane((int)next);
+        if (tile >= F.n_tiles) break;
+        render_tile<MODE>(sc, S, F, tile, lane, stack);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Operator-level kernels on caller-supplied rays
 // ---------------------------------------------------------------------------------------
@@ -431,7 +704,8 @@ __global__ __launch_bounds__(64) void trace_packets_kernel(SceneDev S, int n_pac
     float tt = t[r];
     Hit h;
     h.tri = -1; h.u = 0; h.v = 0;
-    traverse_packet(S, o, d, rd, tt, h, lane);
+    Watch wd{64 * (4 * S.n_node_slots + S.n_tris + 64), nullptr};
+    traverse_packet(global_scene(S), S.n_tris, o, d, rd, tt, h, lane, wd);
     t[r] = tt; tri[r] = h.tri; u[r] = h.u; v[r] = h.v;
 }
 
@@ -447,25 +721,47 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(SceneDev S, int n_rays, 
     float tt = t[r];
     Hit h;
     h.u = 0; h.v = 0;
-    traverse_scalar(S, o, d, tt, h, lds_stack + lane);
+    Watch wd{64 * (4 * S.n_node_slots + S.n_tris + 64), nullptr};
+    traverse_nearest(global_scene(S), S.n_tris, S.coords_ok != 0, o, d, tt, h, (MRT_LDS uint32_t*)lds_stack + lane, wd);
     t[r] = tt; tri[r] = h.tri; u[r] = h.u; v[r] = h.v;
 }
 
 // ---------------------------------------------------------------------------------------
 // Host-callable launchers (used by the C ABI in mrt_api.cpp)
 // ---------------------------------------------------------------------------------------
+size_t resident_scene_bytes(int n_node_slots, int n_tris) {
+    return (size_t)n_node_slots * 32 + (size_t)n_tris * 40 + ((n_tris & 1) ? 8 : 0);
+}
+size_t resident_lds_bytes(int n_node_slots, int n_tris, int stack_entries) {
+    return resident_scene_bytes(n_node_slots, n_tris) + (size_t)(kResidentThreads / 64) * stack_entries * 64 * sizeof(uint16_t);
+}
+
 template <int MODE>
-static hipError_t launch_render_mode(const SceneDev& S, const FrameDev& F, int stack_entries, hipStream_t stream) {
+static hipError_t launch_global_mode(const SceneDev& S, const FrameDev& F, hipStream_t stream) {
     const dim3 grid((unsigned)F.n_tiles), block(64);
-    if (stack_entries <= 16) hipLaunchKernelGGL((render_tiles<MODE, 16>), grid, block, 0, stream, S, F);
-    else if (stack_entries <= 32) hipLaunchKernelGGL((render_tiles<MODE, 32>), grid, block, 0, stream, S, F);
-    else hipLaunchKernelGGL((render_tiles<MODE, kStackDepth>), grid, block, 0, stream, S, F);
+    if (F.stack_entries <= 16) hipLaunchKernelGGL((render_tiles_global<MODE, 16>), grid, block, 0, stream, S, F);
+    else if (F.stack_entries <= 32) hipLaunchKernelGGL((render_tiles_global<MODE, 32>), grid, block, 0, stream, S, F);
+    else hipLaunchKernelGGL((render_tiles_global<MODE, kStackDepth>), grid, block, 0, stream, S, F);
     return hipGetLastError();
 }
 
-hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, int stack_entries, hipStream_t stream) {
+template <int MODE>
+static hipError_t launch_resident_mode(const SceneDev& S, const FrameDev& F, int n_cus, hipStream_t stream) {
+    const size_t lds = resident_lds_bytes(S.n_node_slots, S.n_tris, F.stack_entries);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_tiles_resident<MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+    if (e != hipSuccess) return e;
+    const int waves = kResidentThreads / 64;
+    const int blocks = std::max(1, std::min(n_cus, (F.n_tiles + waves - 1) / waves));
+    hipLaunchKernelGGL((render_tiles_resident<MODE>), dim3((unsigned)blocks), dim3(kResidentThreads), lds, stream, S, F);
+    return hipGetLastError();
+}
+
+// resident: use the LDS-resident persistent kernel (the caller has checked that the scene fits)
+hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool resident, int n_cus, hipStream_t stream) {
     if (F.n_tiles <= 0) return hipSuccess;
-    return mode == 0 ? launch_render_mode<0>(S, F, stack_entries, stream) : launch_render_mode<1>(S, F, stack_entries, stream);
+    if (resident) return mode == 0 ? launch_resident_mode<0>(S, F, n_cus, stream) : launch_resident_mode<1>(S, F, n_cus, stream);
+    return mode == 0 ? launch_global_mode<0>(S, F, stream) : launch_global_mode<1>(S, F, stream);
 }
 
 hipError_t launch_trace_packets(const SceneDev& S, int n_packets, const float* O, const float* D, const float* rD,

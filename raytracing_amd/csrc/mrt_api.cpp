@@ -15,7 +15,8 @@
 #include "raster.h"
 
 namespace mrt {
-hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, int stack_entries, hipStream_t stream);
+hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool resident, int n_cus, hipStream_t stream);
+size_t resident_lds_bytes(int n_node_slots, int n_tris, int stack_entries);
 hipError_t launch_trace_packets(const SceneDev& S, int n_packets, const float* O, const float* D, const float* rD,
                                 float* t, int32_t* tri, float* u, float* v, hipStream_t stream);
 hipError_t launch_trace_rays(const SceneDev& S, int n_rays, int stack_entries, const float* O, const float* D,
@@ -56,7 +57,10 @@ struct mrt_ctx {
     bool has_scene = false;
     int stack_entries = 16;
     HostBVH bvh;
-    DevBuf<float4> d_nodes, d_ltri, d_attr, d_lights;
+    DevBuf<float4> d_nodes, d_triA, d_triB, d_attr, d_lights;
+    DevBuf<float2> d_triC;
+    bool resident = false;      // scene small enough for the LDS-resident kernel
+    int n_cus = 256;
     DevBuf<int4> d_tex;
     DevBuf<uint8_t> d_texels;
     DevBuf<uint32_t> d_pal;
@@ -85,7 +89,7 @@ int fail(mrt_ctx* c, int code, const std::string& msg) {
 
 void refresh_scene_view(mrt_ctx* c) {
     SceneDev& S = c->scene;
-    S.nodes = c->d_nodes.p; S.ltri = c->d_ltri.p; S.attr = c->d_attr.p;
+    S.nodes = c->d_nodes.p; S.triA = c->d_triA.p; S.triB = c->d_triB.p; S.triC = c->d_triC.p; S.attr = c->d_attr.p;
     S.tex = c->d_tex.p; S.texels = c->d_texels.p; S.pal = c->d_pal.p;
     S.lights = c->d_lights.p;
     S.n_lights = (int)(c->lights.size() / 2);
@@ -140,8 +144,9 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
     F.fb = fb_dev;
     F.hit_ids = ids_dev;
     F.counters = c->d_counters.p;
-    MRT_HIP(c, hipMemsetAsync(c->d_counters.p, 0, 4 * sizeof(unsigned long long), stream));
-    MRT_HIP(c, launch_render(c->scene, F, mode, c->stack_entries, stream));
+    F.stack_entries = c->stack_entries;
+    MRT_HIP(c, hipMemsetAsync(c->d_counters.p, 0, kCounterSlots * sizeof(unsigned long long), stream));
+    MRT_HIP(c, launch_render(c->scene, F, mode, c->resident, c->n_cus, stream));
     c->last_stream = stream;
     return MRT_OK;
 }
@@ -168,7 +173,10 @@ int mrt_create(int width, int height, int device, mrt_ctx** out) {
     mrt_ctx* c = new mrt_ctx();
     c->width = width; c->height = height; c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = c->d_counters.ensure(4);
+    if (e == hipSuccess) e = c->d_counters.ensure(kCounterSlots);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) c->n_cus = prop.multiProcessorCount;
     if (e != hipSuccess) {
         std::string msg = std::string("context set-up: ") + hipGetErrorString(e);
         delete c;
@@ -185,7 +193,7 @@ void mrt_destroy(mrt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     if (c->last_stream) { (void)hipStreamSynchronize(c->last_stream); }
-    c->d_nodes.release(); c->d_ltri.release(); c->d_attr.release(); c->d_lights.release();
+    c->d_nodes.release(); c->d_triA.release(); c->d_triB.release(); c->d_triC.release(); c->d_attr.release(); c->d_lights.release();
     c->d_tex.release(); c->d_texels.release(); c->d_pal.release();
     c->d_fb.release(); c->d_ids.release(); c->d_counters.release();
     raster_release(c->raster);
@@ -232,14 +240,22 @@ int mrt_scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt
         nodes[2 * i] = make_float4(B.nmin[i].x, B.nmin[i].y, B.nmin[i].z, bits2f(B.first[i]));
         nodes[2 * i + 1] = make_float4(B.nmax[i].x, B.nmax[i].y, B.nmax[i].z, bits2f(B.count[i]));
     }
-    std::vector<float4> ltri(3 * (size_t)B.n_tris), attr(4 * (size_t)B.n_tris);
+    // exact-division shortcut of the single-ray traversal: every bound must be 0 or of ordinary size
+    bool coords_ok = true;
+    for (size_t i = 0; i < slots && coords_ok; ++i) {
+        if (i == 1 || i == 2) continue;
+        const float c6[6] = {B.nmin[i].x, B.nmin[i].y, B.nmin[i].z, B.nmax[i].x, B.nmax[i].y, B.nmax[i].z};
+        for (float v : c6) coords_ok = coords_ok && div_shortcut_coord_ok(v);
+    }
+    std::vector<float4> triA(B.n_tris), triB(B.n_tris), attr(4 * (size_t)B.n_tris);
+    std::vector<float2> triC(B.n_tris);
     for (uint32_t k = 0; k < B.n_tris; ++k) {
         const uint32_t id = B.idx[k];
         const HostTri& t = B.tris[id];
         const f3 e1 = t.p1 - t.p0, e2 = t.p2 - t.p0;      // raytracer.cpp:289-290
-        ltri[3 * (size_t)k] = make_float4(t.p0.x, t.p0.y, t.p0.z, bits2f(id));
-        ltri[3 * (size_t)k + 1] = make_float4(e1.x, e1.y, e1.z, 0);
-        ltri[3 * (size_t)k + 2] = make_float4(e2.x, e2.y, e2.z, 0);
+        triA[k] = make_float4(t.p0.x, t.p0.y, t.p0.z, e1.x);
+        triB[k] = make_float4(e1.y, e1.z, e2.x, e2.y);
+        triC[k] = make_float2(e2.z, bits2f(id));
     }
     for (uint32_t id = 0; id < B.n_tris; ++id) {
         const HostTri& t = B.tris[id];
@@ -259,7 +275,9 @@ int mrt_scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt
         if (texels.size() > 0x7fffffffu) return fail(c, MRT_E_LIMIT, "textures exceed 2 GiB of texels");
     }
     MRT_HIP(c, c->d_nodes.upload(nodes, c->stream));
-    MRT_HIP(c, c->d_ltri.upload(ltri, c->stream));
+    MRT_HIP(c, c->d_triA.upload(triA, c->stream));
+    MRT_HIP(c, c->d_triB.upload(triB, c->stream));
+    MRT_HIP(c, c->d_triC.upload(triC, c->stream));
     MRT_HIP(c, c->d_attr.upload(attr, c->stream));
     MRT_HIP(c, c->d_tex.upload(tex, c->stream));
     MRT_HIP(c, c->d_texels.upload(texels, c->stream));
@@ -269,6 +287,11 @@ int mrt_scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt
     MRT_HIP(c, hipStreamSynchronize(c->stream));
     refresh_scene_view(c);
     c->scene.n_textures = n_textures;
+    c->scene.n_node_slots = (int)slots;
+    c->scene.coords_ok = coords_ok ? 1 : 0;
+    // LDS residency: nodes + triangles + 16 per-lane stacks must fit one CU's LDS, node indices 16 bits
+    c->resident = B.n_tris > 0 && slots < 65536 &&
+                  resident_lds_bytes((int)slots, (int)B.n_tris, c->stack_entries) + 256 <= (size_t)kLdsBudget;
     c->has_scene = true;
     return MRT_OK;
 }
@@ -314,7 +337,10 @@ int mrt_render(mrt_ctx* c, const float cam[16], uint32_t flags, uint32_t* fb, in
                                 (size_t)c->height, hipMemcpyDeviceToHost, c->stream));
     if (hit_ids)
         MRT_HIP(c, hipMemcpyAsync(hit_ids, c->d_ids.p, npx * g * g * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long wd = 0;
+    MRT_HIP(c, hipMemcpyAsync(&wd, c->d_counters.p + 5, sizeof(wd), hipMemcpyDeviceToHost, c->stream));
     MRT_HIP(c, hipStreamSynchronize(c->stream));
+    if (wd != 0) return fail(c, MRT_E_LIMIT, "a traversal loop exhausted its iteration budget (code " + std::to_string(wd) + ")");
     return MRT_OK;
 }
 
@@ -325,6 +351,9 @@ int mrt_get_ray_counts(mrt_ctx* c, uint64_t out[4]) {
     unsigned long long tmp[4];
     MRT_HIP(c, hipMemcpy(tmp, c->d_counters.p, sizeof(tmp), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; ++i) out[i] = tmp[i];
+    unsigned long long wd = 0;
+    MRT_HIP(c, hipMemcpy(&wd, c->d_counters.p + 5, sizeof(wd), hipMemcpyDeviceToHost));
+    if (wd != 0) return fail(c, MRT_E_LIMIT, "a traversal loop exhausted its iteration budget (code " + std::to_string(wd) + ")");
     return MRT_OK;
 }
 

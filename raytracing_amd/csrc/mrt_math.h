@@ -66,6 +66,35 @@ MRT_HD f3 normalize(f3 v) {
     return v * r;
 }
 
+// ---- exact division by a divisor whose correctly rounded reciprocal is known ------------
+// q = a / d, correctly rounded, from r = RN(1/d): one multiply and two fused residual
+// corrections.  After the first correction the quotient is within one ulp, the residual
+// a - d*q is then exactly representable, and adding residual * r rounds to RN(a/d) (Markstein's
+// final-step theorem) PROVIDED that
+//   - d's significand is not all ones, 2^-40 <= |d| <= 2^12,
+//   - a == 0 or 2^-50 <= |a| <= 2^31   (no overflow, and the residuals stay exact even when
+//     they are subnormal).
+// div_shortcut_dir_ok / div_shortcut_coord_ok test these ranges; coordinates that are 0 or in
+// [2^-27, 2^30] differ by 0 or by at least 2^-50, which is how the range of a = bound - origin
+// is guaranteed without looking at every difference.
+MRT_HD float div_by_recip(float a, float d, float r) {
+    const float q0 = a * r;
+    const float e1 = __builtin_fmaf(-d, q0, a);
+    const float q1 = __builtin_fmaf(e1, r, q0);
+    const float e2 = __builtin_fmaf(-d, q1, a);
+    return __builtin_fmaf(e2, r, q1);
+}
+MRT_HD bool div_shortcut_dir_ok(float d) {
+    uint32_t u;
+    memcpy(&u, &d, 4);
+    const float a = __builtin_fabsf(d);
+    return (a >= 0x1p-40f) && (a <= 0x1p12f) && ((u & 0x7fffffu) != 0x7fffffu);
+}
+MRT_HD bool div_shortcut_coord_ok(float c) {
+    const float a = __builtin_fabsf(c);
+    return (c == 0.0f) || ((a >= 0x1p-27f) && (a <= 0x1p30f));
+}
+
 MRT_HD uint32_t f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 MRT_HD float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
