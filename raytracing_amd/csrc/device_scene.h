@@ -56,13 +56,19 @@ struct FrameDev {
     int grid_g;              // supersampling grid g: 1, 2, 4 or 8
     int pitch;               // output row pitch in pixels
     int stack_entries;       // per-ray traversal stack entries this BVH needs (depth + 2)
+    int stats;               // accumulate the ray counters [0..3] (four atomics per tile)
     uint32_t* fb;            // output frame (output resolution)
     int32_t* hit_ids;        // optional, traced-image resolution
-    // [0] primary rays [1] shadow rays [2] secondary rays [3] primary hits [4] next tile (work counter)
+    // counters[0..15]: [4] next tile (work counter of the resident kernel), [5] watchdog code.
+    // Ray statistics live in kStatSlots groups of 16 words (128 bytes, one cache line each) after
+    // that: group s, word 0 primary rays, 1 shadow rays, 2 secondary rays, 3 primary hits.  A tile
+    // adds into group (tile % kStatSlots) so that the atomics of concurrent waves spread over
+    // many lines instead of queueing on one address; the host sums the groups.
     unsigned long long* counters;
 };
 
-constexpr int kCounterSlots = 8;
+constexpr int kStatSlots = 256;
+constexpr int kCounterSlots = 16 + 16 * kStatSlots;
 constexpr int kStackDepth = 64;        // per-ray traversal stack entries; BVH depth must stay below
 constexpr int kResidentThreads = 1024; // workgroup size of the LDS-resident kernel (16 waves)
 constexpr int kLdsBudget = 160 * 1024; // bytes of LDS per CU on gfx950

@@ -628,14 +628,15 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
             F.fb[(size_t)(y / g) * F.pitch + (x / g)] = out;
         }
     }
-    if (F.counters) {
+    if (F.stats) {
         const uint32_t hits = (uint32_t)__popcll(__ballot(h.tri >= 0));
         const uint32_t sh = wave_sum(n_shadow), se = wave_sum(n_secondary);
         if (lane == 0) {
-            atomicAdd(&F.counters[0], 64ull);
-            if (sh) atomicAdd(&F.counters[1], (unsigned long long)sh);
-            if (se) atomicAdd(&F.counters[2], (unsigned long long)se);
-            if (hits) atomicAdd(&F.counters[3], (unsigned long long)hits);
+            unsigned long long* slot = F.counters + 16 + 16 * (tile % kStatSlots);
+            atomicAdd(&slot[0], 64ull);
+            if (sh) atomicAdd(&slot[1], (unsigned long long)sh);
+            if (se) atomicAdd(&slot[2], (unsigned long long)se);
+            if (hits) atomicAdd(&slot[3], (unsigned long long)hits);
         }
     }
 }

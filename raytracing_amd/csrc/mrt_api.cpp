@@ -3,6 +3,8 @@
 // without a GPU mrt_create fails and nothing else can be called.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <mutex>
 #include <string>
@@ -145,6 +147,7 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
     F.hit_ids = ids_dev;
     F.counters = c->d_counters.p;
     F.stack_entries = c->stack_entries;
+    F.stats = getenv("MRT_NO_STATS") ? 0 : 1;
     MRT_HIP(c, hipMemsetAsync(c->d_counters.p, 0, kCounterSlots * sizeof(unsigned long long), stream));
     MRT_HIP(c, launch_render(c->scene, F, mode, c->resident, c->n_cus, stream));
     c->last_stream = stream;
@@ -292,6 +295,7 @@ int mrt_scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt
     // LDS residency: nodes + triangles + 16 per-lane stacks must fit one CU's LDS, node indices 16 bits
     c->resident = B.n_tris > 0 && slots < 65536 &&
                   resident_lds_bytes((int)slots, (int)B.n_tris, c->stack_entries) + 256 <= (size_t)kLdsBudget;
+    if (const char* e = getenv("MRT_RESIDENT")) c->resident = c->resident && atoi(e) != 0;   // tuning aid: 0 forces the global-memory kernel
     c->has_scene = true;
     return MRT_OK;
 }
@@ -348,11 +352,12 @@ int mrt_get_ray_counts(mrt_ctx* c, uint64_t out[4]) {
     if (!c || !out) return MRT_E_ARG;
     MRT_HIP(c, hipSetDevice(c->device));
     MRT_HIP(c, hipStreamSynchronize(c->last_stream));
-    unsigned long long tmp[4];
-    MRT_HIP(c, hipMemcpy(tmp, c->d_counters.p, sizeof(tmp), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 4; ++i) out[i] = tmp[i];
-    unsigned long long wd = 0;
-    MRT_HIP(c, hipMemcpy(&wd, c->d_counters.p + 5, sizeof(wd), hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> tmp(kCounterSlots);
+    MRT_HIP(c, hipMemcpy(tmp.data(), c->d_counters.p, kCounterSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out[i] = 0;
+    for (int s = 0; s < kStatSlots; ++s)
+        for (int i = 0; i < 4; ++i) out[i] += tmp[16 + 16 * s + i];
+    const unsigned long long wd = tmp[5];
     if (wd != 0) return fail(c, MRT_E_LIMIT, "a traversal loop exhausted its iteration budget (code " + std::to_string(wd) + ")");
     return MRT_OK;
 }

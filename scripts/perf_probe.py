@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Times the frame kernels in isolation (device-resident output, HIP events): packet / recursive,
+with and without lights, for a resolution and pose.  A tuning aid, not part of the benchmark."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--w", type=int, default=1920)
+    ap.add_argument("--h", type=int, default=1080)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--pose", default="P0")
+    args = ap.parse_args()
+    import torch
+    from raytracing_amd import Camera, Raytracer, scene_io
+    scene = scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "maze.mrts"))
+    cam = Camera()
+    if args.pose == "P1":
+        cam.set_position((6, 3, 12))
+        cam.look_at((0, 0, 0))
+    rt = Raytracer(args.w, args.h, device=0)
+    rt.build_bvh(scene)
+    fb = torch.zeros((args.h, args.w), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream()
+    one_light = np.float32([[0, 5, 0, 1, 1, 1, 1]])
+    for lights_name, lights in (("1 light", one_light), ("no light", np.zeros((0, 7), np.float32))):
+        rt.set_lights(lights)
+        for mode, name in ((0, "packet"), (1, "recursive")):
+            for _ in range(3):
+                rt.render_device(cam, fb.data_ptr(), args.w, mode=mode, stream=stream.cuda_stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(args.iters):
+                rt.render_device(cam, fb.data_ptr(), args.w, mode=mode, stream=stream.cuda_stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            c = rt.ray_counts()
+            rays = c["primary"] + c["shadow"] + c["secondary"]
+            print("%-9s %-8s resident=%s  %8.3f ms  %9d rays  %8.1f Mrays/s" % (name, lights_name, os.environ.get("MRT_RESIDENT", "auto"), ms, rays, rays / ms / 1e3))
+
+
+if __name__ == "__main__":
+    main()
