@@ -288,19 +288,21 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
             bool leftN, rightN;
             float tNear, tNear2;
             slab_div_pair(l0, l1, r0, r1, R, shortcut, t, leftN, rightN, tNear, tNear2);
-            if (leftN && rightN) {
-                const bool right_first = tNear2 < tNear;          // raytracer.cpp:1243
-                stack[sp * 64] = right_first ? L : Rr;
-                ++sp;
-                first = right_first ? wbits(r0) : wbits(l0);
-                count = right_first ? wbits(r1) : wbits(l1);
-            } else if (leftN) { first = wbits(l0); count = wbits(l1); }
-            else if (rightN) { first = wbits(r0); count = wbits(r1); }
-            else if (sp == 0) alive = false;
-            else {
-                --sp;
-                const uint32_t n = stack[sp * 64];
-                first = sc.node_first(n); count = sc.node_count(n);
+            // raytracer.cpp:1239-1262 as selects: go right when only the right child passes, or when
+            // both pass and the right one is entered first (tNear2 < tNear); the other passing
+            // child, if any, is deferred; with no passing child the next deferred node is taken.
+            const bool both = leftN && rightN;
+            const bool go_right = rightN && (!leftN || tNear2 < tNear);
+            if (both) { stack[sp * 64] = go_right ? L : Rr; ++sp; }
+            first = go_right ? wbits(r0) : wbits(l0);
+            count = go_right ? wbits(r1) : wbits(l1);
+            if (!(leftN || rightN)) {
+                if (sp == 0) alive = false;
+                else {
+                    --sp;
+                    const uint32_t n = stack[sp * 64];
+                    first = sc.node_first(n); count = sc.node_count(n);
+                }
             }
         }
         if (alive) {

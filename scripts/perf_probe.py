@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--h", type=int, default=1080)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--pose", default="P0")
+    ap.add_argument("--only", default="", help="packet|recursive")
+    ap.add_argument("--lights", default="", help="0|1: only this light count")
     args = ap.parse_args()
     import torch
     from raytracing_amd import Camera, Raytracer, scene_io
@@ -32,8 +34,12 @@ def main():
     stream = torch.cuda.current_stream()
     one_light = np.float32([[0, 5, 0, 1, 1, 1, 1]])
     for lights_name, lights in (("1 light", one_light), ("no light", np.zeros((0, 7), np.float32))):
+        if args.lights and (args.lights == "1") != (len(lights) == 1):
+            continue
         rt.set_lights(lights)
         for mode, name in ((0, "packet"), (1, "recursive")):
+            if args.only and args.only != name:
+                continue
             for _ in range(3):
                 rt.render_device(cam, fb.data_ptr(), args.w, mode=mode, stream=stream.cuda_stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
