@@ -17,26 +17,38 @@ struct RasterTextures {
     const uint32_t* pal;
 };
 
-struct RasterMesh {
-    int verts = 0, tris = 0, texture = -1, tri_base = 0;
-    f3 bounds[2];
-    size_t vert_off = 0, tri_off = 0;    // offsets into the concatenated device arrays
+struct RasterMeshHost {
+    int verts = 0, tris = 0, texture = -1;
+    uint32_t vert_off = 0, tri_off = 0;    // offsets into the concatenated device arrays
+    f3 bounds[2];                          // scenedata.cpp:258-263
+};
+
+// One triangle after set-up: what the coverage and resolve kernels need (device memory).
+struct RasterTri {
+    float px[5], py[5];       // projected polygon (after the two clip planes), up to 5 vertices
+    int n;                    // vertex count, 0 = culled / clipped away
+    int x0, x1, y0, y1;       // pixel bounding box (inclusive), already clamped to the drawable area
+    float zA, zB, zC;         // 1/z      = zA*x + zB*y + zC
+    float uA, uB, uC;         // u/z      likewise
+    float vA, vB, vC;         // v/z      likewise
+    int texture, level;       // texture index and palette level (0..31)
 };
 
 struct RasterState {
-    std::vector<RasterMesh> meshes;
-    float* d_pos = nullptr;      // all vertices, 3 floats each
-    float* d_uv = nullptr;       // 2 floats each
-    float* d_N = nullptr;        // per triangle, 3 floats
-    int32_t* d_tri = nullptr;    // per triangle, 3 vertex indices (mesh-local)
-    int32_t* d_tri_mesh = nullptr;   // per triangle, mesh index
-    size_t n_verts = 0, n_tris = 0;
+    std::vector<RasterMeshHost> meshes;
+    float* d_pos = nullptr;          // all vertices, 3 floats each
+    float* d_uv = nullptr;           // 2 floats each
+    float* d_N = nullptr;            // per triangle, 3 floats
+    int32_t* d_tri = nullptr;        // per triangle, 3 vertex indices into d_pos/d_uv (already offset)
+    int32_t* d_tri_tex = nullptr;    // per triangle: texture index, or -1 when its mesh is culled / untextured
+    RasterTri* d_setup = nullptr;
+    uint32_t n_verts = 0, n_tris = 0;
+    std::vector<int32_t> h_tri_mesh; // per triangle: mesh index
     unsigned long long* d_depth = nullptr;   // W*H packed {orderable 1/z, triangle index}
     uint32_t* d_fb = nullptr;
     float* d_z = nullptr;
     int32_t* d_ids = nullptr;
     size_t frame_px = 0;
-    void* d_meshinfo = nullptr;
 };
 
 int raster_upload(RasterState& R, const mrt_mesh* meshes, int n_meshes, hipStream_t stream, std::string& err);
