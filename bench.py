@@ -37,17 +37,10 @@ FLOPS_FIXED_PRIMARY, FLOPS_FIXED_SECONDARY = 40, 30
 VALU_PEAK_TFLOPS = 157.3 / 2                # fp32 vector peak counts FMA as 2; this path may not fuse
 
 
-def band_rows(height, world, rank):
-    """Contiguous tile-row ranges: the first (rows % world) ranks get one extra 8-pixel row."""
-    rows = height // 8
-    base, rem = divmod(rows, world)
-    start = rank * base + min(rank, rem)
-    return start * 8, (start + base + (1 if rank < rem else 0)) * 8
-
-
 class Workload:
     def __init__(self, name, scene, width, height, mode, grid, cam, rank, world, torch, dist):
         from raytracing_amd import Raytracer
+        from raytracing_amd.multigpu import band_rows
         self.name, self.W, self.H, self.mode, self.grid, self.cam = name, width, height, mode, grid, cam
         self.rank, self.world, self.torch, self.dist = rank, world, torch, dist
         self.rt = Raytracer(width, height, device=torch.cuda.current_device())
@@ -69,18 +62,8 @@ class Workload:
             e1.record(stream)
             self.events.append((e0, e1))
         if self.world > 1:
-            dist = self.dist
-            ops = []
-            if self.rank == 0:
-                for r in range(1, self.world):
-                    a, b = band_rows(self.H, self.world, r)
-                    if b > a:
-                        ops.append(dist.P2POp(dist.irecv, self.fb[a:b], r))
-            elif self.y1 > self.y0:
-                ops.append(dist.P2POp(dist.isend, self.fb[self.y0:self.y1], 0))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
+            from raytracing_amd.multigpu import gather_bands
+            gather_bands(self.fb, self.world, self.rank, self.dist)
 
     def run(self, steps, warmup):
         torch, dist = self.torch, self.dist

@@ -4,5 +4,5 @@
 container.  The compute path is HIP only -- importing this package never falls back to a CPU
 implementation.
 """
-from . import binding, scene_io  # noqa: F401
+from . import binding, multigpu, scene_io  # noqa: F401
 from .binding import Camera, MrtError, Raytracer, MODE_PACKET, MODE_RECURSIVE  # noqa: F401

@@ -1,0 +1,78 @@
+// Headless stand-in for the reference's application loop (game.cpp:15-35 Init, :84-113 Tick):
+// loads the scene, builds the BVH, renders frames with the ray tracer or the rasterizer and
+// reports frame time and ray throughput the way the reference's overlay does (game.cpp:95-112).
+//
+//   mrt_game [--scene assets/maze.obj | scene.mrts] [--size W H] [--frames N]
+//            [--mode packet|recursive|raster] [--pos x y z --lookat x y z]
+//            [--out frame.ppm] [--dump-scene out.mrts] [--device N]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "mrt_host.hpp"
+
+using namespace mrt_host;
+
+int main(int argc, char** argv) {
+    std::string scene_file = "assets/maze.obj", mode = "packet", out, dump;
+    int W = 800, H = 600, frames = 10, device = -1;       // game.h:3-4
+    bool have_pose = false;
+    vec3 pos{0, 0, 0}, target{0, 0, -1};
+    for (int i = 1; i < argc; ++i) {
+        auto need = [&](int n) { if (i + n >= argc) { fprintf(stderr, "missing value after %s\n", argv[i]); exit(2); } };
+        if (!strcmp(argv[i], "--scene")) { need(1); scene_file = argv[++i]; }
+        else if (!strcmp(argv[i], "--size")) { need(2); W = atoi(argv[++i]); H = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--frames")) { need(1); frames = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--mode")) { need(1); mode = argv[++i]; }
+        else if (!strcmp(argv[i], "--out")) { need(1); out = argv[++i]; }
+        else if (!strcmp(argv[i], "--dump-scene")) { need(1); dump = argv[++i]; }
+        else if (!strcmp(argv[i], "--device")) { need(1); device = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--pos")) { need(3); pos = {(float)atof(argv[i + 1]), (float)atof(argv[i + 2]), (float)atof(argv[i + 3])}; i += 3; have_pose = true; }
+        else if (!strcmp(argv[i], "--lookat")) { need(3); target = {(float)atof(argv[i + 1]), (float)atof(argv[i + 2]), (float)atof(argv[i + 3])}; i += 3; have_pose = true; }
+        else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
+    }
+    try {
+        Scene scene;
+        scene.Add(scene_file);                                  // game.cpp:19
+        if (scene_file.size() < 5 || scene_file.substr(scene_file.size() - 5) != ".mrts") scene.ApplyReferenceMaterials();
+        size_t tris = 0;
+        for (const Mesh& m : scene.meshList) tris += m.tris();
+        printf("scene %s: %zu meshes, %zu triangles, %zu textures\n", scene_file.c_str(), scene.meshList.size(), tris, scene.texList.size());
+        if (!dump.empty()) { scene.SaveMRTS(dump); printf("wrote %s\n", dump.c_str()); return 0; }
+
+        Surface screen(W, H);                                   // template.cpp:98
+        Camera camera;
+        if (have_pose) { camera.SetPosition(pos); camera.LookAt(target); }
+        Raytracer raytracer;
+        raytracer.Init(&screen, device);                        // game.cpp:17-18
+        auto t0 = std::chrono::steady_clock::now();
+        raytracer.BuildBVH(scene);                              // game.cpp:34
+        printf("BuildBVH + upload: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+
+        double total_ms = 0, best_ms = 1e30;
+        uint64_t rays[4] = {0, 0, 0, 0};
+        for (int f = 0; f < frames; ++f) {                      // Game::Tick
+            screen.Clear(0);                                    // game.cpp:87
+            t0 = std::chrono::steady_clock::now();
+            if (mode == "packet") raytracer.Render(camera);
+            else if (mode == "recursive") raytracer.RenderRecursive(camera);
+            else if (mode == "raster") raytracer.RenderRaster(camera);
+            else { fprintf(stderr, "unknown mode %s\n", mode.c_str()); return 2; }
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (f > 0 || frames == 1) { total_ms += ms; best_ms = ms < best_ms ? ms : best_ms; }
+        }
+        const int counted = frames > 1 ? frames - 1 : 1;
+        if (mode != "raster") raytracer.RayCounts(rays);
+        const double n_rays = (double)(rays[0] + rays[1] + rays[2]);
+        printf("Frametime : %f ms (best %f), FPS : %.1f", total_ms / counted, best_ms, 1000.0 * counted / total_ms);
+        if (n_rays > 0) printf(", %.0f rays/frame, %.1f Mrays/s (host framebuffer copy included)", n_rays, n_rays / best_ms / 1e3);
+        printf("\n");
+        if (!out.empty() && screen.SavePPM(out)) printf("wrote %s\n", out.c_str());
+    } catch (const std::exception& e) {
+        fprintf(stderr, "mrt_game: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

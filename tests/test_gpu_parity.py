@@ -227,3 +227,24 @@ def test_error_paths(maze_scene):
     with pytest.raises(MrtError, match="texture"):
         rt.build_bvh(bad)
     rt.close()
+
+
+def test_cpp_host_driver_renders_reference_frame(tmp_path, known):
+    """The headless C++ driver (Game::Init + Tick order through the host mirror classes) writes the
+    frame whose hash the reference recorded: 800x600, default camera, packet path."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "raytracing_amd", "host", "mrt_game")
+    out = str(tmp_path / "frame.ppm")
+    subprocess.check_call([exe, "--scene", os.path.join(ROOT, "tests", "golden", "maze.mrts"), "--size", "800", "600", "--frames", "2",
+                           "--mode", "packet", "--out", out])
+    with open(out, "rb") as f:
+        assert f.readline() == b"P6\n" and f.readline() == b"800 600\n" and f.readline() == b"255\n"
+        rgb = np.frombuffer(f.read(), np.uint8).reshape(600, 800, 3).astype(np.uint32)
+    rt = Raytracer(800, 600, device=0)
+    rt.build_bvh(scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "maze.mrts")))
+    fb, _ = rt.render(oracle_lib.IDENTITY, mode=MODE_PACKET)
+    rt.close()
+    assert "%016x" % oracle_lib.fbhash(fb) == known["packet_frames"][1]["fbhash"]
+    assert np.array_equal((rgb[..., 0] << 16) | (rgb[..., 1] << 8) | rgb[..., 2], fb & 0xFFFFFF)

@@ -143,3 +143,30 @@ def test_soup_generator_follows_the_lcg():
                   -(vals[:, 2] * np.float32(40)) - np.float32(3)], 1)
     p0 = c + (vals[:, 3:6] - np.float32(0.5)) * sz
     assert np.array_equal(bits(s["meshes"][0]["pos"][0::3]), bits(p0.astype(np.float32)))
+
+
+DRIVER = os.path.join(ROOT, "raytracing_amd", "host", "mrt_game")
+
+
+@pytest.mark.skipif(not (os.path.isdir(oracle_lib.REF_ASSETS) and os.path.exists(DRIVER)), reason="reference assets or driver not present")
+def test_host_obj_loader_reproduces_fixture(tmp_path):
+    """The C++ host layer's OBJ/MTL/.bin loader (Scene::Add) gives byte for byte the scene that
+    the oracle's restatement of the reference loader gives."""
+    import subprocess
+    out = str(tmp_path / "maze.mrts")
+    subprocess.check_call([DRIVER, "--scene", "assets/maze.obj", "--dump-scene", out], cwd=os.path.dirname(oracle_lib.REF_ASSETS),
+                          stdout=subprocess.DEVNULL)
+    with open(out, "rb") as a, open(os.path.join(ROOT, "tests", "golden", "maze.mrts"), "rb") as b:
+        assert a.read() == b.read()
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="driver not built")
+def test_host_driver_reports_missing_gpu_or_file(tmp_path):
+    import subprocess
+    import torch
+    r = subprocess.run([DRIVER, "--scene", str(tmp_path / "nope.obj")], capture_output=True, text=True)
+    assert r.returncode == 1 and "File not found" in r.stderr
+    if not torch.cuda.is_available():
+        r = subprocess.run([DRIVER, "--scene", os.path.join(ROOT, "tests", "golden", "maze.mrts"), "--frames", "1"],
+                           capture_output=True, text=True)
+        assert r.returncode == 1 and "no HIP device" in r.stderr

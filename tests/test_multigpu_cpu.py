@@ -1,0 +1,69 @@
+"""The multi-GPU frame split on CPU: two gloo ranks, bands rendered by the oracle, gathered with the
+same send/recv code the GPU benchmark uses, compared with the undivided frame."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def test_band_rows_cover_the_frame_exactly():
+    from raytracing_amd.multigpu import band_rows
+    for h in (8, 64, 1080, 4320, 600):
+        for world in (1, 2, 3, 4, 8, 200):
+            bands = [band_rows(h, world, r) for r in range(world)]
+            assert bands[0][0] == 0 and bands[-1][1] == h
+            for (a, b), (c, d) in zip(bands, bands[1:]):
+                assert b == c and a % 8 == 0 and b % 8 == 0 and a <= b
+            sizes = [b - a for a, b in bands]
+            assert max(sizes) - min(sizes) <= 8
+    assert [band_rows(4320, 8, r)[1] - band_rows(4320, 8, r)[0] for r in range(8)] == [544] * 4 + [536] * 4
+    with pytest.raises(ValueError):
+        band_rows(601, 2, 0)
+
+
+def _worker(rank, world, port, W, H, out_path):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib
+    from raytracing_amd import scene_io
+    from raytracing_amd.multigpu import band_rows, gather_bands
+    scene = scene_io.load_scene(os.path.join(HERE, "golden", "maze.mrts"))
+    o = oracle_lib.Oracle()
+    o.add_scene(scene)
+    o.build_bvh()
+    cam = oracle_lib.lookat((6, 3, 12), (0, 0, 0))
+    y0, y1 = band_rows(H, world, rank)
+    band = o.render(cam, W, H, mode=0, rows=(y0, y1), want_ids=False)["fb"]     # only rows [y0,y1) are written
+    fb = torch.zeros((H, W), dtype=torch.int32)
+    fb[y0:y1] = torch.from_numpy(band[y0:y1].view(np.int32))
+    gather_bands(fb, world, rank, dist)
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, fb.numpy().view(np.uint32))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_rank_band_gather_equals_full_frame(tmp_path, world, maze_oracle):
+    import oracle_lib
+    W, H = 160, 104          # 13 tile rows: uneven bands
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "fb.npy")
+    mp.spawn(_worker, args=(world, port, W, H, out), nprocs=world, join=True)
+    got = np.load(out)
+    ref = maze_oracle.render(oracle_lib.lookat((6, 3, 12), (0, 0, 0)), W, H, mode=0, want_ids=False)["fb"]
+    assert np.array_equal(got, ref)
