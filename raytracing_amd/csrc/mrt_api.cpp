@@ -73,6 +73,9 @@ struct mrt_ctx {
     DevBuf<int32_t> d_ids;
     DevBuf<unsigned long long> d_counters;
     hipStream_t last_stream = nullptr;
+    // page-locked staging for the synchronous entry point: device -> pinned at PCIe rate, then a host copy
+    void* h_stage = nullptr;
+    size_t h_stage_bytes = 0;
     // rasterizer
     RasterState raster;
 };
@@ -200,6 +203,7 @@ void mrt_destroy(mrt_ctx* c) {
     c->d_tex.release(); c->d_texels.release(); c->d_pal.release();
     c->d_fb.release(); c->d_ids.release(); c->d_counters.release();
     raster_release(c->raster);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -337,13 +341,23 @@ int mrt_render(mrt_ctx* c, const float cam[16], uint32_t flags, uint32_t* fb, in
     if (hit_ids) MRT_HIP(c, c->d_ids.ensure(npx * g * g));
     if (int rc = render_common(c, cam, flags, 0, c->height, c->d_fb.p, c->width, hit_ids ? c->d_ids.p : nullptr, c->stream))
         return rc;
-    MRT_HIP(c, hipMemcpy2DAsync(fb, (size_t)pitch_px * 4, c->d_fb.p, (size_t)c->width * 4, (size_t)c->width * 4,
-                                (size_t)c->height, hipMemcpyDeviceToHost, c->stream));
-    if (hit_ids)
-        MRT_HIP(c, hipMemcpyAsync(hit_ids, c->d_ids.p, npx * g * g * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    unsigned long long wd = 0;
-    MRT_HIP(c, hipMemcpyAsync(&wd, c->d_counters.p + 5, sizeof(wd), hipMemcpyDeviceToHost, c->stream));
+    const size_t fb_bytes = npx * 4, id_bytes = hit_ids ? npx * g * g * sizeof(int32_t) : 0, need = fb_bytes + id_bytes + 64;
+    if (c->h_stage_bytes < need) {
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->h_stage = nullptr; c->h_stage_bytes = 0;
+        MRT_HIP(c, hipHostMalloc(&c->h_stage, need, hipHostMallocDefault));
+        c->h_stage_bytes = need;
+    }
+    unsigned char* stage = static_cast<unsigned char*>(c->h_stage);
+    unsigned long long* wd_stage = reinterpret_cast<unsigned long long*>(stage + fb_bytes + id_bytes);
+    MRT_HIP(c, hipMemcpyAsync(stage, c->d_fb.p, fb_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (hit_ids) MRT_HIP(c, hipMemcpyAsync(stage + fb_bytes, c->d_ids.p, id_bytes, hipMemcpyDeviceToHost, c->stream));
+    MRT_HIP(c, hipMemcpyAsync(wd_stage, c->d_counters.p + 5, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     MRT_HIP(c, hipStreamSynchronize(c->stream));
+    if (pitch_px == c->width) memcpy(fb, stage, fb_bytes);
+    else for (int y = 0; y < c->height; ++y) memcpy(fb + (size_t)y * pitch_px, stage + (size_t)y * c->width * 4, (size_t)c->width * 4);
+    if (hit_ids) memcpy(hit_ids, stage + fb_bytes, id_bytes);
+    const unsigned long long wd = *wd_stage;
     if (wd != 0) return fail(c, MRT_E_LIMIT, "a traversal loop exhausted its iteration budget (code " + std::to_string(wd) + ")");
     return MRT_OK;
 }

@@ -1,0 +1,49 @@
+// Host-side check of mrt::div_by_recip (raytracing_amd/csrc/mrt_math.h) against IEEE division:
+// random and adversarial operands inside the documented ranges must give bit-identical
+// quotients.  Prints "mismatches=<n>"; exit status 0 iff n == 0.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../raytracing_amd/csrc/mrt_math.h"
+
+static uint64_t s = 88172645463325252ull;
+static inline uint64_t rnd() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+static inline float mk(uint32_t sign, int e, uint32_t m) {
+    uint32_t u = (sign << 31) | ((uint32_t)(e + 127) << 23) | (m & 0x7fffffu);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+int main(int argc, char** argv) {
+    const long N = argc > 1 ? atol(argv[1]) : 20000000;
+    long bad = 0, tested = 0;
+    for (long i = 0; i < N; ++i) {
+        const uint64_t x = rnd(), y = rnd();
+        // |a| in [2^-50, 2^31], |d| in [2^-40, 2^12]; mantissas biased towards the extremes one time in eight
+        uint32_t ma = (uint32_t)(y & 0x7fffffu), md = (uint32_t)((y >> 23) & 0x7fffffu);
+        if ((x >> 20) % 8 == 0) md = ((x >> 24) & 1) ? 0x7ffffeu - (uint32_t)((y >> 50) % 8) : (uint32_t)((y >> 50) % 16);
+        if ((x >> 28) % 8 == 0) ma = ((x >> 32) & 1) ? 0x7fffffu - (uint32_t)((y >> 54) % 8) : (uint32_t)((y >> 54) % 16);
+        float a = mk((uint32_t)(x >> 63), (int)(x % 81) - 50, ma);
+        float d = mk((uint32_t)((x >> 62) & 1), (int)((x >> 8) % 52) - 40, md);
+        if ((x >> 36) % 64 == 0) a = ((x >> 42) & 1) ? 0.0f : -0.0f;
+        if (!mrt::div_shortcut_dir_ok(d)) continue;
+        const float r = 1.0f / d;
+        const float want = a / d, got = mrt::div_by_recip(a, d, r);
+        ++tested;
+        // a zero quotient may differ in sign (no box predicate can see it); everything else is bit-exact
+        if (memcmp(&want, &got, 4) && !(want == 0.0f && got == 0.0f)) {
+            if (bad < 5) printf("a=%a d=%a want=%a got=%a\n", a, d, want, got);
+            ++bad;
+        }
+    }
+    // range predicates
+    if (mrt::div_shortcut_dir_ok(0.0f) || mrt::div_shortcut_dir_ok(mk(0, 0, 0x7fffffu)) || mrt::div_shortcut_dir_ok(1e-20f) ||
+        !mrt::div_shortcut_dir_ok(-0.5f) || !mrt::div_shortcut_coord_ok(0.0f) || !mrt::div_shortcut_coord_ok(-17.8125f) ||
+        mrt::div_shortcut_coord_ok(1e-12f) || mrt::div_shortcut_coord_ok(4e9f) || mrt::div_shortcut_coord_ok(__builtin_nanf("")))
+        ++bad;
+    printf("tested=%ld mismatches=%ld\n", tested, bad);
+    return bad == 0 ? 0 : 1;
+}

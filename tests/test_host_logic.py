@@ -170,3 +170,15 @@ def test_host_driver_reports_missing_gpu_or_file(tmp_path):
         r = subprocess.run([DRIVER, "--scene", os.path.join(ROOT, "tests", "golden", "maze.mrts"), "--frames", "1"],
                            capture_output=True, text=True)
         assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+def test_exact_division_shortcut_matches_ieee_division(tmp_path):
+    """mrt::div_by_recip (the 5-operation quotient used by the single-ray traversal instead of 12
+    true divisions per node) against `/` on 20 million operand pairs inside its documented ranges."""
+    import subprocess
+    exe = str(tmp_path / "check_div")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-mfma", "-o", exe,
+                           os.path.join(ROOT, "tests", "native", "check_div.cpp")])
+    r = subprocess.run([exe, "20000000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "mismatches=0" in r.stdout
