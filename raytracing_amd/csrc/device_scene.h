@@ -59,16 +59,20 @@ struct FrameDev {
     int stats;               // accumulate the ray counters [0..3] (four atomics per tile)
     uint32_t* fb;            // output frame (output resolution)
     int32_t* hit_ids;        // optional, traced-image resolution
-    // counters[0..15]: [4] next tile (work counter of the resident kernel), [5] watchdog code.
+    // counters[0..15]: [5] watchdog code.  counters[kQueueBase + 16*q]: next index of tile queue q
+    // (resident kernel), one cache line per queue.
     // Ray statistics live in kStatSlots groups of 16 words (128 bytes, one cache line each) after
-    // that: group s, word 0 primary rays, 1 shadow rays, 2 secondary rays, 3 primary hits.  A tile
+    // the queues: group s, word 0 primary rays, 1 shadow rays, 2 secondary rays, 3 primary hits.  A tile
     // adds into group (tile % kStatSlots) so that the atomics of concurrent waves spread over
     // many lines instead of queueing on one address; the host sums the groups.
     unsigned long long* counters;
 };
 
 constexpr int kStatSlots = 256;
-constexpr int kCounterSlots = 16 + 16 * kStatSlots;
+constexpr int kTileQueues = 32;
+constexpr int kQueueBase = 16;
+constexpr int kStatBase = kQueueBase + 16 * kTileQueues;
+constexpr int kCounterSlots = kStatBase + 16 * kStatSlots;
 constexpr int kStackDepth = 64;        // per-ray traversal stack entries; BVH depth must stay below
 constexpr int kResidentThreads = 1024; // workgroup size of the LDS-resident kernel (16 waves)
 constexpr int kLdsBudget = 160 * 1024; // bytes of LDS per CU on gfx950

@@ -19,6 +19,8 @@
 // this file must be compiled with -ffp-contract=off and without fast-math.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "device_scene.h"
@@ -216,6 +218,15 @@ struct LaneStack3 {
 template <class SC>
 __device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, f3 D, f3 rD, float& t, Hit& h, int lane, Watch& wd) {
     if (n_tris == 0) return;
+    // With every 1/D component finite, (bound - O) * rD is never a NaN, and hardware min/max
+    // then give the predicates the same values as glm's compare+select (up to the sign of a
+    // zero, which no comparison sees).  A wave holding an axis-parallel ray (1/0 = inf) takes
+    // the compare+select form.
+    const bool finite = !__any(!(fabsf(rD.x) < INFINITY && fabsf(rD.y) < INFINITY && fabsf(rD.z) < INFINITY));
+    auto terms = [&](f3 bmin, f3 bmax, float& tn, float& tf) {
+        if (finite) slab_terms_finite((bmin - O) * rD, (bmax - O) * rD, tn, tf);
+        else slab_terms((bmin - O) * rD, (bmax - O) * rD, tn, tf);
+    };
     LaneStack1 work;
     work.push(lane, 0u);                       // scan(root, f = 0): raytracer.cpp:1351-1357
     while (work.sp > 0) {
@@ -224,8 +235,9 @@ __device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, 
         uint32_t node = e >> 6;
         const int f = (int)(e & 63u);
         const v4f n0 = sc.node(2 * node), n1 = sc.node(2 * node + 1);
-        float tn;
-        const bool pass = slab_mul(xyz(n0), xyz(n1), O, rD, t, tn);
+        float tn, tf;
+        terms(xyz(n0), xyz(n1), tn, tf);
+        const bool pass = slab_pass(tn, tf, t);
         unsigned long long mask = __ballot(pass) & (~0ull << f);
         if (mask == 0) continue;
         int i = __ffsll((long long)mask) - 1;
@@ -244,8 +256,8 @@ __device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, 
             const uint32_t L = first, R = first + 1;
             const v4f l0 = sc.node(2 * L), l1 = sc.node(2 * L + 1), r0 = sc.node(2 * R), r1 = sc.node(2 * R + 1);
             float tnl, tfl, tnr, tfr;
-            slab_terms((xyz(l0) - O) * rD, (xyz(l1) - O) * rD, tnl, tfl);
-            slab_terms((xyz(r0) - O) * rD, (xyz(r1) - O) * rD, tnr, tfr);
+            terms(xyz(l0), xyz(l1), tnl, tfl);
+            terms(xyz(r0), xyz(r1), tnr, tfr);
             const bool right_first = lane_bcast(tnr, i) < lane_bcast(tnl, i);   // raytracer.cpp:1384
             work.push(lane, ((right_first ? L : R) << 6) | (uint32_t)i);
             const bool p = right_first ? slab_pass(tnr, tfr, t) : slab_pass(tnl, tfl, t);
@@ -634,7 +646,7 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
         const uint32_t hits = (uint32_t)__popcll(__ballot(h.tri >= 0));
         const uint32_t sh = wave_sum(n_shadow), se = wave_sum(n_secondary);
         if (lane == 0) {
-            unsigned long long* slot = F.counters + 16 + 16 * (tile % kStatSlots);
+            unsigned long long* slot = F.counters + kStatBase + 16 * (tile % kStatSlots);
             atomicAdd(&slot[0], 64ull);
             if (sh) atomicAdd(&slot[1], (unsigned long long)sh);
             if (se) atomicAdd(&slot[2], (unsigned long long)se);
@@ -650,8 +662,8 @@ __device__ __forceinline__ SceneGlobal global_scene(const SceneDev& S) {
 
 // Scene in global memory: one 64-thread workgroup (one wave) per tile.  SD = stack entries.
 template <int MODE, int SD>
-__global__ __launch_bounds__(64) void render_tiles_global(SceneDev S, FrameDev F) {
-    __shared__ uint32_t lds_stack[SD * 64];
+__global__ __launch_bounds__(64, MODE == 0 ? 8 : 4) void render_tiles_global(SceneDev S, FrameDev F) {
+    __shared__ uint32_t lds_stack[MODE == 0 ? 64 : SD * 64];      // only the single-ray traversal keeps a per-lane stack
     const int lane = threadIdx.x;
     const int tile = blockIdx.x;
     if (tile >= F.n_tiles) return;
@@ -684,11 +696,20 @@ __global__ __launch_bounds__(kResidentThreads) void render_tiles_resident(SceneD
     const SceneLds sc{l_nodes, l_a, l_b, l_c};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     MRT_LDS uint16_t* stack = l_stacks + (size_t)wave * F.stack_entries * 64 + lane;
-    for (int pulls = 0; pulls <= F.n_tiles; ++pulls) {      // no wave can draw more tiles than exist
+    // Tile queue.  One shared counter would serialise every pull of every wave on one address
+    // (tens of thousands of returning atomics per frame); instead the tiles are dealt round-robin
+    // into kTileQueues queues, each with its own counter on its own cache line.  A workgroup
+    // starts on queue (blockIdx % kTileQueues) and moves on to the next queue when one runs dry,
+    // so all tiles are drawn exactly once whatever the placement of the workgroups.
+    const int n_queues = F.n_tiles < kTileQueues ? 1 : kTileQueues;
+    int q = (int)(blockIdx.x % (unsigned)n_queues), dry = 0;
+    for (int pulls = 0; pulls <= F.n_tiles + n_queues && dry < n_queues; ++pulls) {   // bounded: no wave can draw more
         unsigned long long next = 0;
-        if (lane == 0) next = atomicAdd(&F.counters[4], 1ull);
-        const int tile = __builtin_amdgcn_readfirstlane((int)next);
-        if (tile >= F.n_tiles) break;
+        if (lane == 0) next = atomicAdd(&F.counters[kQueueBase + 16 * q], 1ull);
+        const int idx = __builtin_amdgcn_readfirstlane((int)next);
+        const int tile = idx * n_queues + q;
+        if (tile >= F.n_tiles) { q = (q + 1 == n_queues) ? 0 : q + 1; ++dry; continue; }
+        dry = 0;
         render_tile<MODE>(sc, S, F, tile, lane, stack);
     }
 }
@@ -754,9 +775,11 @@ static hipError_t launch_resident_mode(const SceneDev& S, const FrameDev& F, int
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_tiles_resident<MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
     if (e != hipSuccess) return e;
-    const int waves = kResidentThreads / 64;
+    int threads = kResidentThreads;
+    if (const char* e = getenv("MRT_RESIDENT_THREADS")) threads = std::max(64, std::min(kResidentThreads, atoi(e) / 64 * 64));   // tuning aid
+    const int waves = threads / 64;
     const int blocks = std::max(1, std::min(n_cus, (F.n_tiles + waves - 1) / waves));
-    hipLaunchKernelGGL((render_tiles_resident<MODE>), dim3((unsigned)blocks), dim3(kResidentThreads), lds, stream, S, F);
+    hipLaunchKernelGGL((render_tiles_resident<MODE>), dim3((unsigned)blocks), dim3((unsigned)threads), lds, stream, S, F);
     return hipGetLastError();
 }
 

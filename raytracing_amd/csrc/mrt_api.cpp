@@ -370,7 +370,7 @@ int mrt_get_ray_counts(mrt_ctx* c, uint64_t out[4]) {
     MRT_HIP(c, hipMemcpy(tmp.data(), c->d_counters.p, kCounterSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; ++i) out[i] = 0;
     for (int s = 0; s < kStatSlots; ++s)
-        for (int i = 0; i < 4; ++i) out[i] += tmp[16 + 16 * s + i];
+        for (int i = 0; i < 4; ++i) out[i] += tmp[kStatBase + 16 * s + i];
     const unsigned long long wd = tmp[5];
     if (wd != 0) return fail(c, MRT_E_LIMIT, "a traversal loop exhausted its iteration budget (code " + std::to_string(wd) + ")");
     return MRT_OK;

@@ -25,8 +25,11 @@ struct RasterMeshHost {
 
 // One triangle after set-up: what the coverage and resolve kernels need (device memory).
 struct RasterTri {
-    float px[5], py[5];       // projected polygon (after the two clip planes), up to 5 vertices
-    int n;                    // vertex count, 0 = culled / clipped away
+    // polygon edges after the two clip planes (up to 5), each oriented top to bottom:
+    // x(y) = ex + dx * (y - ey) on rows iy0..iy1 (rasterizer.cpp:146-160)
+    float ex[5], ey[5], dx[5];
+    int iy0[5], iy1[5];
+    int n;                    // edge count, 0 = culled / clipped away
     int x0, x1, y0, y1;       // pixel bounding box (inclusive), already clamped to the drawable area
     float zA, zB, zC;         // 1/z      = zA*x + zB*y + zC
     float uA, uB, uC;         // u/z      likewise
@@ -42,6 +45,10 @@ struct RasterState {
     int32_t* d_tri = nullptr;        // per triangle, 3 vertex indices into d_pos/d_uv (already offset)
     int32_t* d_tri_tex = nullptr;    // per triangle: texture index, or -1 when its mesh is culled / untextured
     RasterTri* d_setup = nullptr;
+    uint2* d_chunks = nullptr;       // work items of the coverage kernel: {triangle, first 8x8 block}
+    size_t chunk_capacity = 0;
+    uint32_t* d_chunk_base = nullptr; // per triangle: first chunk slot
+    uint32_t* d_total = nullptr;     // [0] chunks needed this frame
     uint32_t n_verts = 0, n_tris = 0;
     std::vector<int32_t> h_tri_mesh; // per triangle: mesh index
     unsigned long long* d_depth = nullptr;   // W*H packed {orderable 1/z, triangle index}
@@ -49,6 +56,8 @@ struct RasterState {
     float* d_z = nullptr;
     int32_t* d_ids = nullptr;
     size_t frame_px = 0;
+    void* h_stage = nullptr;          // page-locked staging for the frame coming back
+    size_t h_stage_bytes = 0;
 };
 
 int raster_upload(RasterState& R, const mrt_mesh* meshes, int n_meshes, hipStream_t stream, std::string& err);

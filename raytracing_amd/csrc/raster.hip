@@ -3,7 +3,10 @@
 //   raster_setup    one thread per triangle: vertex transform, back-face cull, Sutherland-Hodgman
 //                   clip against the near and left planes, projection, palette level, and the
 //                   screen-space plane equations of 1/z, u/z and v/z (rasterizer.cpp:100-141).
-//   raster_cover    one wave per triangle walks the triangle's pixel bounding box in 8x8 blocks;
+//   raster_emit     cuts every triangle's pixel bounding box into chunks of kChunkBlocks 8x8 blocks
+//                   and appends one work item per chunk, so a screen-filling triangle is spread
+//                   over hundreds of waves while a small one costs a single wave.
+//   raster_cover    one wave per chunk, one lane per pixel of an 8x8 block;
 //                   a pixel is covered exactly when the reference's scan conversion would plot it
 //                   (rows y0 < y <= y1 of the spanning edges, columns xl < x <= xr of the row's
 //                   extent, rasterizer.cpp:143-182), and the depth test is a 64-bit atomicMin on
@@ -27,6 +30,8 @@ struct RasterFrame {
     float frustum[2][4];     // clip planes 0 (near) and 1 (left): rasterizer.cpp:37-38
     int W, H;
 };
+
+constexpr uint32_t kUncovered = 0xff000000u;
 
 __device__ __forceinline__ unsigned int orderable(float f) {
     const unsigned int u = __float_as_uint(f);
@@ -95,7 +100,6 @@ __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* 
                     iz[v] = 1.0f / p.z;                                        // :151
                     uz[v] = cuv[from][v].x * iz[v];                            // :152-153
                     vz[v] = cuv[from][v].y * iz[v];
-                    T.px[v] = sx[v]; T.py[v] = sy[v];
                     xmin = fminf(xmin, sx[v]); xmax = fmaxf(xmax, sx[v]);
                     ymin = fminf(ymin, sy[v]); ymax = fmaxf(ymax, sy[v]);
                 }
@@ -123,7 +127,20 @@ __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* 
                     T.y1 = min(H - 2, (int)fminf(ymax, (float)H));
                     T.x0 = max(0, (int)fmaxf(xmin, -1.0f) + 1);
                     T.x1 = min(W - 2, (int)fminf(xmax, (float)W));
-                    if (T.y0 <= T.y1 && T.x0 <= T.x1) T.n = nin;
+                    if (T.y0 <= T.y1 && T.x0 <= T.x1) {
+                        int ne = 0;
+                        for (int j = 0; j < nin; ++j) {                      // rasterizer.cpp:143-151
+                            int a = j, b2 = (j + 1 == nin) ? 0 : j + 1;
+                            if (sy[a] > sy[b2]) { const int h = a; a = b2; b2 = h; }
+                            const float ya = sy[a], yb = sy[b2];
+                            if ((ya == yb) || (ya >= H) || (yb < 1)) continue;
+                            const float rydiff = 1.0f / (yb - ya);
+                            T.ex[ne] = sx[a]; T.ey[ne] = ya; T.dx[ne] = (sx[b2] - sx[a]) * rydiff;
+                            T.iy0[ne] = max(1, (int)ya + 1); T.iy1[ne] = min(H - 2, (int)yb);
+                            if (T.iy0[ne] <= T.iy1[ne]) ++ne;
+                        }
+                        T.n = ne;
+                    }
                 }
             }
         }
@@ -131,22 +148,15 @@ __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* 
     out[i] = T;
 }
 
-// Is pixel (x, y) plotted by the reference's scan conversion of this polygon?  Returns the row
-// extent test of rasterizer.cpp:143-170: every edge contributes to the rows y0 < y <= y1 it
-// spans; the row's extent is [min x, max x] over those edges; columns (int)xl+1 .. (int)xr.
-__device__ __forceinline__ bool covers(const RasterTri& T, int x, int y, int W, int H) {
+// Is pixel (x, y) plotted by the reference's scan conversion of this polygon?  The row extent of
+// rasterizer.cpp:143-170: every edge contributes to the rows it spans; the row's extent is
+// [min x, max x] over those edges; columns (int)xl+1 .. min(W-2, (int)xr).
+__device__ __forceinline__ bool covers(const RasterTri& T, int x, int y, int W) {
     float xl = (float)(W - 1), xr = 0.0f;             // the outline tables' idle values, :28, :164
     bool any = false;
     for (int j = 0; j < T.n; ++j) {
-        int a = j, b = (j + 1 == T.n) ? 0 : j + 1;
-        if (T.py[a] > T.py[b]) { const int h = a; a = b; b = h; }
-        const float y0 = T.py[a], y1 = T.py[b];
-        if ((y0 == y1) || (y0 >= H) || (y1 < 1)) continue;
-        const int iy0 = max(1, (int)y0 + 1), iy1 = min(H - 2, (int)y1);
-        if (y < iy0 || y > iy1) continue;
-        const float rydiff = 1.0f / (y1 - y0);
-        const float dx = (T.px[b] - T.px[a]) * rydiff;
-        const float xe = T.px[a] + dx * ((float)y - y0);
+        if (y < T.iy0[j] || y > T.iy1[j]) continue;
+        const float xe = T.ex[j] + T.dx[j] * ((float)y - T.ey[j]);
         if (xe < xl) xl = xe;
         if (xe > xr) xr = xe;
         any = true;
@@ -156,23 +166,51 @@ __device__ __forceinline__ bool covers(const RasterTri& T, int x, int y, int W, 
     return x >= ix0 && x <= ix1;
 }
 
-__global__ __launch_bounds__(64) void raster_cover(const RasterTri* setup, uint32_t n_tris, unsigned long long* depth, int W, int H) {
-    const uint32_t t = blockIdx.x;
+constexpr int kChunkBlocks = 16;     // 8x8 blocks per coverage work item
+
+__device__ __forceinline__ uint32_t tri_blocks(const RasterTri& T) {
+    if (T.n == 0) return 0;
+    const uint32_t bw = (uint32_t)((T.x1 >> 3) - (T.x0 >> 3) + 1), bh = (uint32_t)((T.y1 >> 3) - (T.y0 >> 3) + 1);
+    return bw * bh;
+}
+
+// pass 1: reserve chunk slots per triangle
+__global__ __launch_bounds__(256) void raster_count(const RasterTri* setup, uint32_t n_tris, uint32_t* chunk_base, uint32_t* total) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tris) return;
+    const uint32_t nb = tri_blocks(setup[t]);
+    const uint32_t nc = (nb + kChunkBlocks - 1) / kChunkBlocks;
+    chunk_base[t] = nc ? atomicAdd(total, nc) : 0u;
+}
+// pass 2: write the work items
+__global__ __launch_bounds__(256) void raster_emit(const RasterTri* setup, uint32_t n_tris, const uint32_t* chunk_base, uint2* chunks) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tris) return;
+    const uint32_t nb = tri_blocks(setup[t]);
+    const uint32_t nc = (nb + kChunkBlocks - 1) / kChunkBlocks;
+    for (uint32_t c = 0; c < nc; ++c) chunks[chunk_base[t] + c] = make_uint2(t, c * kChunkBlocks);
+}
+
+__global__ __launch_bounds__(64) void raster_cover(const RasterTri* setup, const uint2* chunks, uint32_t n_chunks,
+                                                   unsigned long long* depth, int W, int H) {
+    if (blockIdx.x >= n_chunks) return;
+    const uint2 item = chunks[blockIdx.x];
+    const uint32_t t = item.x;
     const RasterTri T = setup[t];
-    if (T.n == 0) return;
     const int lane = threadIdx.x;
-    const int bx0 = T.x0 & ~7, by0 = T.y0 & ~7;
-    for (int by = by0; by <= T.y1; by += 8)
-        for (int bx = bx0; bx <= T.x1; bx += 8) {
-            const int x = bx + (lane & 7), y = by + (lane >> 3);
-            if (x < T.x0 || x > T.x1 || y < T.y0 || y > T.y1) continue;
-            if (!covers(T, x, y, W, H)) continue;
-            const float z0 = T.zA * (float)x + T.zB * (float)y + T.zC;
-            if (!(z0 < 0.0f)) continue;                     // the z-buffer is cleared to 0 and the test is "z0 >= zbuf: skip" (:55, :177)
-            const unsigned long long key = ((unsigned long long)orderable(z0) << 32) | t;
-            atomicMin(&depth[(size_t)y * W + x], key);
-        }
+    const int bx0 = T.x0 >> 3, by0 = T.y0 >> 3;
+    const uint32_t bw = (uint32_t)((T.x1 >> 3) - bx0 + 1);
+    const uint32_t nb = tri_blocks(T);
+    const uint32_t end = min(item.y + (uint32_t)kChunkBlocks, nb);
+    for (uint32_t b = item.y; b < end; ++b) {
+        const int x = ((bx0 + (int)(b % bw)) << 3) + (lane & 7), y = ((by0 + (int)(b / bw)) << 3) + (lane >> 3);
+        if (x < T.x0 || x > T.x1 || y < T.y0 || y > T.y1) continue;
+        if (!covers(T, x, y, W)) continue;
+        const float z0 = T.zA * (float)x + T.zB * (float)y + T.zC;
+        if (!(z0 < 0.0f)) continue;                     // the z-buffer is cleared to 0 and the test is "z0 >= zbuf: skip" (:55, :177)
+        const unsigned long long key = ((unsigned long long)orderable(z0) << 32) | t;
+        atomicMin(&depth[(size_t)y * W + x], key);
+    }
 }
 
 __global__ __launch_bounds__(256) void raster_resolve(const RasterTri* setup, const unsigned long long* depth, RasterTextures tx,
@@ -185,7 +223,7 @@ __global__ __launch_bounds__(256) void raster_resolve(const RasterTri* setup, co
     if (t == 0xffffffffu) {
         if (zbuf) zbuf[p] = 0.0f;
         if (ids) ids[p] = -1;
-        fb[p] = 0;                       // the caller's cleared frame (game.cpp:87)
+        fb[p] = kUncovered;              // palette entries are 0x00RRGGBB, so this value marks "nothing drawn here"
         return;
     }
     const RasterTri T = setup[t];
@@ -220,8 +258,10 @@ __global__ void raster_clear(unsigned long long* depth, size_t n) {
 
 void raster_release(RasterState& R) {
     for (void* p : {(void*)R.d_pos, (void*)R.d_uv, (void*)R.d_N, (void*)R.d_tri, (void*)R.d_tri_tex, (void*)R.d_setup,
+                    (void*)R.d_chunks, (void*)R.d_chunk_base, (void*)R.d_total,
                     (void*)R.d_depth, (void*)R.d_fb, (void*)R.d_z, (void*)R.d_ids})
         if (p) (void)hipFree(p);
+    if (R.h_stage) (void)hipHostFree(R.h_stage);
     R = RasterState();
 }
 
@@ -256,6 +296,8 @@ int raster_upload(RasterState& R, const mrt_mesh* meshes, int n_meshes, hipStrea
     RASTER_HIP(hipMalloc((void**)&R.d_tri, tri.size() * 4));
     RASTER_HIP(hipMalloc((void**)&R.d_tri_tex, (size_t)R.n_tris * 4));
     RASTER_HIP(hipMalloc((void**)&R.d_setup, (size_t)R.n_tris * sizeof(RasterTri)));
+    RASTER_HIP(hipMalloc((void**)&R.d_chunk_base, (size_t)R.n_tris * 4));
+    RASTER_HIP(hipMalloc((void**)&R.d_total, 16));
     RASTER_HIP(hipMemcpyAsync(R.d_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, stream));
     RASTER_HIP(hipMemcpyAsync(R.d_uv, uv.data(), uv.size() * 4, hipMemcpyHostToDevice, stream));
     RASTER_HIP(hipMemcpyAsync(R.d_N, N.data(), N.size() * 4, hipMemcpyHostToDevice, stream));
@@ -329,24 +371,51 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
         RASTER_HIP(hipMemcpyAsync(R.d_tri_tex, tri_tex.data(), (size_t)R.n_tris * 4, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(raster_setup, dim3((R.n_tris + 255) / 256), dim3(256), 0, stream, F, R.d_pos, R.d_uv, R.d_N, R.d_tri,
                            R.d_tri_tex, R.d_setup, R.n_tris);
-        hipLaunchKernelGGL(raster_cover, dim3(R.n_tris), dim3(64), 0, stream, R.d_setup, R.n_tris, R.d_depth, W, H);
+        RASTER_HIP(hipMemsetAsync(R.d_total, 0, 4, stream));
+        hipLaunchKernelGGL(raster_count, dim3((R.n_tris + 255) / 256), dim3(256), 0, stream, R.d_setup, R.n_tris, R.d_chunk_base, R.d_total);
+        uint32_t n_chunks = 0;
+        RASTER_HIP(hipMemcpyAsync(&n_chunks, R.d_total, 4, hipMemcpyDeviceToHost, stream));
+        RASTER_HIP(hipStreamSynchronize(stream));
+        if (n_chunks > R.chunk_capacity) {
+            if (R.d_chunks) (void)hipFree(R.d_chunks);
+            R.d_chunks = nullptr; R.chunk_capacity = 0;
+            const size_t cap = (size_t)n_chunks + n_chunks / 4 + 1024;
+            RASTER_HIP(hipMalloc((void**)&R.d_chunks, cap * sizeof(uint2)));
+            R.chunk_capacity = cap;
+        }
+        if (n_chunks > 0) {
+            hipLaunchKernelGGL(raster_emit, dim3((R.n_tris + 255) / 256), dim3(256), 0, stream, R.d_setup, R.n_tris, R.d_chunk_base, R.d_chunks);
+            hipLaunchKernelGGL(raster_cover, dim3(n_chunks), dim3(64), 0, stream, R.d_setup, R.d_chunks, n_chunks, R.d_depth, W, H);
+        }
     }
     hipLaunchKernelGGL(raster_resolve, dim3((unsigned)((W + 255) / 256), (unsigned)H), dim3(256), 0, stream, R.d_setup, R.d_depth, tx,
-                       R.d_fb, R.d_z, R.d_ids, W, H);
+                       R.d_fb, zbuf ? R.d_z : nullptr, tri_ids ? R.d_ids : nullptr, W, H);
     RASTER_HIP(hipGetLastError());
-    // pixels no triangle covers are left as the caller had them: copy only covered pixels on the host
-    std::vector<uint32_t> h_fb(npx);
-    std::vector<int32_t> h_ids(npx);
-    RASTER_HIP(hipMemcpyAsync(h_fb.data(), R.d_fb, npx * 4, hipMemcpyDeviceToHost, stream));
-    RASTER_HIP(hipMemcpyAsync(h_ids.data(), R.d_ids, npx * 4, hipMemcpyDeviceToHost, stream));
-    if (zbuf) RASTER_HIP(hipMemcpyAsync(zbuf, R.d_z, npx * 4, hipMemcpyDeviceToHost, stream));
-    RASTER_HIP(hipStreamSynchronize(stream));      // tri_tex and the staging vectors go out of scope after this
-    for (int y = 0; y < H; ++y)
-        for (int x = 0; x < W; ++x) {
-            const size_t p = (size_t)y * W + x;
-            if (h_ids[p] >= 0) fb[(size_t)y * pitch_px + x] = h_fb[p];
-        }
-    if (tri_ids) memcpy(tri_ids, h_ids.data(), npx * 4);
+    // Pixels no triangle covers are left as the caller had them (the reference only plots covered
+    // pixels): the frame comes back through page-locked staging and covered pixels are merged in.
+    const size_t need = npx * 4 + (tri_ids ? npx * 4 : 0) + (zbuf ? npx * 4 : 0);
+    if (R.h_stage_bytes < need) {
+        if (R.h_stage) (void)hipHostFree(R.h_stage);
+        R.h_stage = nullptr; R.h_stage_bytes = 0;
+        RASTER_HIP(hipHostMalloc(&R.h_stage, need, hipHostMallocDefault));
+        R.h_stage_bytes = need;
+    }
+    unsigned char* stage = static_cast<unsigned char*>(R.h_stage);
+    uint32_t* h_fb = reinterpret_cast<uint32_t*>(stage);
+    unsigned char* next = stage + npx * 4;
+    RASTER_HIP(hipMemcpyAsync(h_fb, R.d_fb, npx * 4, hipMemcpyDeviceToHost, stream));
+    if (tri_ids) { RASTER_HIP(hipMemcpyAsync(next, R.d_ids, npx * 4, hipMemcpyDeviceToHost, stream)); }
+    unsigned char* ids_stage = next;
+    if (tri_ids) next += npx * 4;
+    if (zbuf) RASTER_HIP(hipMemcpyAsync(next, R.d_z, npx * 4, hipMemcpyDeviceToHost, stream));
+    RASTER_HIP(hipStreamSynchronize(stream));      // tri_tex goes out of scope after this
+    for (int y = 0; y < H; ++y) {
+        const uint32_t* src = h_fb + (size_t)y * W;
+        uint32_t* dst = fb + (size_t)y * pitch_px;
+        for (int x = 0; x < W; ++x) dst[x] = src[x] == kUncovered ? dst[x] : src[x];
+    }
+    if (tri_ids) memcpy(tri_ids, ids_stage, npx * 4);
+    if (zbuf) memcpy(zbuf, next, npx * 4);
     return MRT_OK;
 }
 
