@@ -19,7 +19,11 @@ Rank 0 prints one JSON line.  Besides the contract's keys it carries
   packet_path   -- the reference's live Render path (64-ray packets + shadow rays) at 1080p,
                    GPU and CPU, which is the path the >= 50x target is stated on;
   c4_8k_16spp   -- 7680x4320 with a 4x4 sample grid (packet path), the multi-GPU configuration,
-                   measured at every N so its scaling can be read from the same files.
+                   measured at every N so its scaling can be read from the same files;
+  c3_1m_tris_4k -- synthetic 1,000,000-triangle soup at 3840x2160, packet path (scene in global
+                   memory, divergent traversal);
+  c5_raster_1m_4k -- the rasterizer path on the same soup (rank 0 only; host framebuffer copy
+                   included because that path has no device-resident entry point).
 """
 import argparse
 import json
@@ -212,6 +216,22 @@ def main():
             out["c4_8k_16spp"] = {"workload": "same scene, 7680x4320, 4x4 sample grid (30720x17280 traced), packet path",
                                   "value": round(r4["mrays_per_s"], 3), "unit": "Mrays/s", "ms_per_step": round(r4["ms_per_step"], 4),
                                   "kernel_ms": round(r4["kernel_ms"], 4), "rays_per_frame": r4["rays_per_frame"]}
+        del pk, c4
+        soup = scene_io.soup_scene(1000000)
+        c3 = Workload("c3", soup, 3840, 2160, MODE_PACKET, 1, cam, rank, world, torch, dist)
+        r3 = c3.run(max(2, min(args.steps, 10)), 2)
+        if rank == 0:
+            out["c3_1m_tris_4k"] = {"workload": "synthetic 1,000,000-triangle soup (LCG seed 12345), 3840x2160, packet path + shadow rays",
+                                    "value": round(r3["mrays_per_s"], 3), "unit": "Mrays/s", "ms_per_step": round(r3["ms_per_step"], 4),
+                                    "kernel_ms": round(r3["kernel_ms"], 4), "rays_per_frame": r3["rays_per_frame"]}
+            fbh = np.zeros((2160, 3840), np.uint32)
+            c3.rt.raster(cam, fb=fbh, want_z=False, want_ids=False)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                c3.rt.raster(cam, fb=fbh, want_z=False, want_ids=False)
+            out["c5_raster_1m_4k"] = {"workload": "rasterizer path, same soup, 3840x2160, host framebuffer copy included",
+                                      "ms_per_frame": round((time.perf_counter() - t0) / 5 * 1e3, 3),
+                                      "covered_fraction": round(float((fbh != 0).mean()), 4)}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -42,6 +42,13 @@ def main():
         c = rt.ray_counts()
         rays = c["primary"] + c["shadow"] + c["secondary"]
         print("%-9s %dx%d  %.3f ms/frame  %d rays  %.1f Mrays/s" % (name, W, H, ms, rays, rays / ms / 1e3), flush=True)
+    # rasterizer path on the same scene (host framebuffer included: the C ABI has no device-resident raster entry)
+    fbh = np.zeros((H, W), np.uint32)
+    rt.raster(cam, fb=fbh, want_z=False, want_ids=False)
+    t0 = time.time()
+    for _ in range(3):
+        rt.raster(cam, fb=fbh, want_z=False, want_ids=False)
+    print("raster    %dx%d  %.2f ms/frame (host copy included), %.1f %% of pixels covered" % (W, H, (time.time() - t0) / 3 * 1e3, 100.0 * (fbh != 0).mean()), flush=True)
     if check:
         o = oracle_lib.Oracle()
         o.add_scene(scene)
@@ -55,6 +62,15 @@ def main():
         got, ids = rt.render(cam, mode=0)
         print("hit ids equal:", np.array_equal(ids, ref["ids"]), " pixels equal:", np.array_equal(got, ref["fb"]),
               " hits:", int((ids >= 0).sum()), flush=True)
+        t0 = time.time()
+        rref = o.raster(cam, W, H)
+        print("oracle raster frame %.2f s" % (time.time() - t0), flush=True)
+        gfb, gz, gids = rt.raster(cam)
+        n = W * H
+        print("raster: coverage differs on %d px (%.4f %%), winner differs on %d px (%.4f %%), colour differs on %d px (%.4f %%)" % (
+            int(((gids >= 0) != (rref["ids"] >= 0)).sum()), 100.0 * ((gids >= 0) != (rref["ids"] >= 0)).mean(),
+            int((gids != rref["ids"]).sum()), 100.0 * (gids != rref["ids"]).mean(),
+            int((gfb != rref["fb"]).sum()), 100.0 * (gfb != rref["fb"]).mean()), flush=True)
 
 
 if __name__ == "__main__":
