@@ -153,6 +153,9 @@ __device__ __forceinline__ void tri_test(v4f A, v4f B, v2f C, f3 O, f3 D, float&
     const f3 p0 = {A.x, A.y, A.z}, e1 = {A.w, B.x, B.y}, e2 = {B.z, B.w, C.x};
     const f3 pvec = cross(D, e2);
     const float det = dot(e1, pvec);
+    if (WAVE_REJECT) {
+        if (!__any(!(det < -kEpsilon))) return;          // back-facing for every ray of the wave
+    }
     const f3 tvec = O - p0;
     const float un = dot(tvec, pvec);
     const f3 qvec = cross(tvec, e1);
@@ -246,9 +249,17 @@ __device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, 
             if (wd.expired(2)) break;
             if (count != 0) {
                 if (lane >= i) {
-                    for (uint32_t k = first; k < first + count; ++k) {
+                    // the next triangle's record is requested before the current one is tested
+                    v4f A = sc.tri_a(first), B = sc.tri_b(first);
+                    v2f C = sc.tri_c(first);
+                    const uint32_t last = first + count - 1;
+                    for (uint32_t k = first; k <= last; ++k) {
                         if (wd.expired(64)) break;
-                        tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h);
+                        const uint32_t kn = k < last ? k + 1 : k;
+                        const v4f An = sc.tri_a(kn), Bn = sc.tri_b(kn);
+                        const v2f Cn = sc.tri_c(kn);
+                        tri_test<true>(A, B, C, O, D, t, h);
+                        A = An; B = Bn; C = Cn;
                     }
                 }
                 break;
@@ -368,10 +379,17 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
         const uint32_t first = sc.node_first(node), count = sc.node_count(node);
         if (count != 0) {
             if ((m >> lane) & 1ull) {
-                for (uint32_t k = first; k < first + count; ++k) {
+                v4f A = sc.tri_a(first), B = sc.tri_b(first);
+                v2f C = sc.tri_c(first);
+                const uint32_t last = first + count - 1;
+                for (uint32_t k = first; k <= last; ++k) {
                     if (wd.expired(256)) break;
-                    if (h.tri < 0) tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h);
+                    const uint32_t kn = k < last ? k + 1 : k;
+                    const v4f An = sc.tri_a(kn), Bn = sc.tri_b(kn);
+                    const v2f Cn = sc.tri_c(kn);
+                    if (h.tri < 0) tri_test<true>(A, B, C, O, D, t, h);
                     if (!__any(h.tri < 0)) break;
+                    A = An; B = Bn; C = Cn;
                 }
             }
             found = __ballot(h.tri >= 0);
