@@ -115,6 +115,22 @@ int mrt_render_device(mrt_ctx* ctx, const float cam_to_world[16], uint32_t flags
                       int y_begin, int y_end, void* fb_dev, int pitch_px,
                       void* hit_ids_dev, void* stream);
 
+/* The same launch for one share of an INTERLEAVED split of the frame.  The reference deals 8x8
+ * tiles to its workers one at a time from a shared counter (threads.cpp:158-169), which balances
+ * cheap sky tiles against expensive ones; the counterpart across GPUs is to deal 8-row tile rows
+ * in blocks: share `part` of `n_parts` renders the tile rows R with
+ * (R / block_tile_rows) % n_parts == part, in increasing order.  compact = 0: each row is written
+ * at its place in the frame (fb_dev + y*pitch_px).  compact = 1: the share's rows are written
+ * packed, its k-th pixel row at fb_dev + k*pitch_px (the buffer a rank sends to rank 0);
+ * hit_ids_dev follows the same choice.  mrt_part_rows gives the number of pixel rows of a share. */
+int mrt_render_device_part(mrt_ctx* ctx, const float cam_to_world[16], uint32_t flags,
+                           int part, int n_parts, int block_tile_rows, int compact,
+                           void* fb_dev, int pitch_px, void* hit_ids_dev, void* stream);
+
+/* Pixel rows in share `part` of the split above for a frame of `height` rows (no context needed);
+ * negative on bad arguments. */
+int mrt_part_rows(int height, int part, int n_parts, int block_tile_rows);
+
 /* Rasterizer::Render(camera) (game.cpp:93; rasterizer.cpp:53-184).  fb as above; zbuf
  * optional host width*height floats receiving the 1/z buffer (rasterizer.cpp:12,55);
  * tri_ids optional host width*height, depth-winner triangle index, -1 = uncovered.

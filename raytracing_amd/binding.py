@@ -18,7 +18,8 @@ MODE_PACKET = 0
 MODE_RECURSIVE = 1
 
 SYMBOLS = ("mrt_create", "mrt_destroy", "mrt_last_error", "mrt_version", "mrt_scene_upload", "mrt_set_lights",
-           "mrt_bvh_build_host", "mrt_render", "mrt_render_device", "mrt_raster_render", "mrt_trace_packets",
+           "mrt_bvh_build_host", "mrt_render", "mrt_render_device", "mrt_render_device_part", "mrt_part_rows",
+           "mrt_raster_render", "mrt_trace_packets",
            "mrt_trace_rays", "mrt_get_ray_counts", "mrt_camera_look_at")
 
 
@@ -74,6 +75,8 @@ def lib():
         L.mrt_bvh_build_host.argtypes = [C.POINTER(_Mesh), i32, vp, vp, vp, vp]
         L.mrt_render.argtypes = [vp, vp, C.c_uint32, vp, i32, vp]
         L.mrt_render_device.argtypes = [vp, vp, C.c_uint32, i32, i32, vp, i32, vp, vp]
+        L.mrt_render_device_part.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, i32, vp, i32, vp, vp]
+        L.mrt_part_rows.argtypes = [i32, i32, i32, i32]
         L.mrt_raster_render.argtypes = [vp, vp, vp, i32, vp, vp]
         L.mrt_trace_packets.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
         L.mrt_trace_rays.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
@@ -201,6 +204,15 @@ class Raytracer:
         self._check(self.L.mrt_render_device(self.h, _p(cam), flags(mode, spp_grid), y0, y1, C.c_void_p(fb_ptr), pitch,
                                              C.c_void_p(ids_ptr) if ids_ptr else None,
                                              C.c_void_p(stream) if stream else None), "mrt_render_device")
+
+    def render_device_part(self, cam, fb_ptr, pitch, part, n_parts, block_tile_rows=1, compact=False, mode=MODE_PACKET,
+                           spp_grid=1, ids_ptr=None, stream=None):
+        """One share of the interleaved tile-row split (multi-GPU): see mrt_render_device_part."""
+        cam = np.ascontiguousarray(getattr(cam, "transform", cam), np.float32).reshape(16)
+        self._check(self.L.mrt_render_device_part(self.h, _p(cam), flags(mode, spp_grid), part, n_parts, block_tile_rows,
+                                                  1 if compact else 0, C.c_void_p(fb_ptr), pitch,
+                                                  C.c_void_p(ids_ptr) if ids_ptr else None,
+                                                  C.c_void_p(stream) if stream else None), "mrt_render_device_part")
 
     def ray_counts(self):
         out = np.zeros(4, np.uint64)

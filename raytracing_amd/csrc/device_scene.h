@@ -51,8 +51,13 @@ struct FrameDev {
     float inv_w, inv_h;
     int width, height;       // of the traced image (output size times the supersampling grid)
     int tiles_x;             // width / 8
-    int tile_y0;             // first tile row of this launch
+    int tile_y0;             // first tile row of this launch (contiguous band, n_parts <= 1)
     int n_tiles;             // tiles in this launch
+    // Interleaved share of the frame (n_parts > 1): this launch renders the OUTPUT tile rows R
+    // (8 output rows each) with (R / part_block) % n_parts == part, in increasing order.  With
+    // `compact` set, the rows are written packed (the launch's k-th row of pixels at row k of
+    // fb / hit_ids) instead of at their place in the frame.
+    int part, n_parts, part_block, compact;
     int grid_g;              // supersampling grid g: 1, 2, 4 or 8
     int pitch;               // output row pitch in pixels
     int stack_entries;       // per-ray traversal stack entries this BVH needs (depth + 2)
@@ -72,7 +77,14 @@ constexpr int kStatSlots = 256;
 constexpr int kTileQueues = 32;
 constexpr int kQueueBase = 16;
 constexpr int kStatBase = kQueueBase + 16 * kTileQueues;
+#ifdef MRT_LOOP_COUNTS
+// Diagnostic build only (make prof): per-site loop iteration counts, wave level and lane level.
+constexpr int kProfSites = 16;
+constexpr int kProfBase = kStatBase + 16 * kStatSlots;
+constexpr int kCounterSlots = kProfBase + 2 * kProfSites;
+#else
 constexpr int kCounterSlots = kStatBase + 16 * kStatSlots;
+#endif
 constexpr int kStackDepth = 64;        // per-ray traversal stack entries; BVH depth must stay below
 constexpr int kResidentThreads = 1024; // workgroup size of the LDS-resident kernel (16 waves)
 constexpr int kLdsBudget = 160 * 1024; // bytes of LDS per CU on gfx950

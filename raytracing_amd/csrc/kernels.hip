@@ -45,6 +45,18 @@ struct Hit { int tri; float u, v; };
 struct Watch {
     int left;
     unsigned long long* flag;
+#ifdef MRT_LOOP_COUNTS
+    uint32_t wave_n[kProfSites] = {}, lane_n[kProfSites] = {};
+    // one tick per wave-level execution of a site (counted on the first active lane) and one per lane
+    __device__ __forceinline__ void tick(int site) {
+        const int me = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (__ffsll((long long)__ballot(1)) - 1 == me) ++wave_n[site];
+        ++lane_n[site];
+    }
+#define MRT_TICK(wd, site) (wd).tick(site)
+#else
+#define MRT_TICK(wd, site) ((void)0)
+#endif
     __device__ __forceinline__ bool expired(unsigned long long code) {
         if (--left >= 0) return false;
         if (flag) atomicOr(flag, code);
@@ -149,13 +161,14 @@ __device__ __forceinline__ void slab_div_pair(v4f l0, v4f l1, v4f r0, v4f r1, co
 // issued only when some lane cannot be ruled out that way.
 // ---------------------------------------------------------------------------------------
 template <bool WAVE_REJECT>
-__device__ __forceinline__ void tri_test(v4f A, v4f B, v2f C, f3 O, f3 D, float& t, Hit& h) {
+__device__ __forceinline__ void tri_test(v4f A, v4f B, v2f C, f3 O, f3 D, float& t, Hit& h, Watch& wd) {
     const f3 p0 = {A.x, A.y, A.z}, e1 = {A.w, B.x, B.y}, e2 = {B.z, B.w, C.x};
     const f3 pvec = cross(D, e2);
     const float det = dot(e1, pvec);
     if (WAVE_REJECT) {
         if (!__any(!(det < -kEpsilon))) return;          // back-facing for every ray of the wave
     }
+    MRT_TICK(wd, WAVE_REJECT ? 6 : 12);
     const f3 tvec = O - p0;
     const float un = dot(tvec, pvec);
     const f3 qvec = cross(tvec, e1);
@@ -170,6 +183,7 @@ __device__ __forceinline__ void tri_test(v4f A, v4f B, v2f C, f3 O, f3 D, float&
         clear_miss = clear_miss && (fabsf(det) >= 1e-30f);   // tiny determinants: always decide exactly
         if (!__any(!clear_miss)) return;
     }
+    MRT_TICK(wd, WAVE_REJECT ? 7 : 13);
     if (det < -kEpsilon) return;
     const float invDet = 1 / det;
     const float u = un * invDet;
@@ -234,6 +248,7 @@ __device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, 
     work.push(lane, 0u);                       // scan(root, f = 0): raytracer.cpp:1351-1357
     while (work.sp > 0) {
         if (wd.expired(1)) break;
+        MRT_TICK(wd, 8);
         const uint32_t e = work.pop();
         uint32_t node = e >> 6;
         const int f = (int)(e & 63u);
@@ -255,15 +270,17 @@ __device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, 
                     const uint32_t last = first + count - 1;
                     for (uint32_t k = first; k <= last; ++k) {
                         if (wd.expired(64)) break;
+                        MRT_TICK(wd, 10);
                         const uint32_t kn = k < last ? k + 1 : k;
                         const v4f An = sc.tri_a(kn), Bn = sc.tri_b(kn);
                         const v2f Cn = sc.tri_c(kn);
-                        tri_test<true>(A, B, C, O, D, t, h);
+                        tri_test<true>(A, B, C, O, D, t, h, wd);
                         A = An; B = Bn; C = Cn;
                     }
                 }
                 break;
             }
+            MRT_TICK(wd, 9);
             const uint32_t L = first, R = first + 1;
             const v4f l0 = sc.node(2 * L), l1 = sc.node(2 * L + 1), r0 = sc.node(2 * R), r1 = sc.node(2 * R + 1);
             float tnl, tfl, tnr, tfr;
@@ -297,6 +314,7 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
         float tn;
         if (!slab_mul(xyz(root0), xyz(root1), O, D, t, tn)) return false;
     }
+    MRT_TICK(wd, 2);
     const RayDiv R = make_ray_div(O, D, coords_ok);
     const bool shortcut = __all(R.shortcut);
     int sp = 0;
@@ -306,6 +324,7 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
         if (wd.expired(4)) break;
         while (alive && count == 0) {
             if (wd.expired(8)) { alive = false; break; }
+            MRT_TICK(wd, 0);
             const uint32_t L = first, Rr = first + 1;
             const v4f l0 = sc.node(2 * L), l1 = sc.node(2 * L + 1), r0 = sc.node(2 * Rr), r1 = sc.node(2 * Rr + 1);
             bool leftN, rightN;
@@ -331,7 +350,8 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
         if (alive) {
             for (uint32_t k = first; k < first + count; ++k) {
                 if (wd.expired(128)) break;
-                tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h);
+                MRT_TICK(wd, 1);
+                tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
             }
             if (sp == 0) alive = false;
             else {
@@ -376,6 +396,7 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
         work.pop(node, m);
         m &= ~found;
         if (m == 0) continue;
+        MRT_TICK(wd, 3);
         const uint32_t first = sc.node_first(node), count = sc.node_count(node);
         if (count != 0) {
             if ((m >> lane) & 1ull) {
@@ -384,10 +405,11 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
                 const uint32_t last = first + count - 1;
                 for (uint32_t k = first; k <= last; ++k) {
                     if (wd.expired(256)) break;
+                    MRT_TICK(wd, 5);
                     const uint32_t kn = k < last ? k + 1 : k;
                     const v4f An = sc.tri_a(kn), Bn = sc.tri_b(kn);
                     const v2f Cn = sc.tri_c(kn);
-                    if (h.tri < 0) tri_test<true>(A, B, C, O, D, t, h);
+                    if (h.tri < 0) tri_test<true>(A, B, C, O, D, t, h, wd);
                     if (!__any(h.tri < 0)) break;
                     A = An; B = Bn; C = Cn;
                 }
@@ -396,6 +418,7 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
         } else {
             const uint32_t L = first, Rr = first + 1;
             const v4f l0 = sc.node(2 * L), l1 = sc.node(2 * L + 1), r0 = sc.node(2 * Rr), r1 = sc.node(2 * Rr + 1);
+            MRT_TICK(wd, 4);
             bool leftN, rightN;
             float a, b;
             slab_div_pair(l0, l1, r0, r1, R, shortcut, INFINITY, leftN, rightN, a, b);
@@ -514,6 +537,7 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
     ShadeState F;
     while (__any(tracing)) {
         if (wd.expired(32)) break;
+        MRT_TICK(wd, 11);
         Hit h;
         h.tri = -1; h.u = 0; h.v = 0;
         float t = tmax;
@@ -610,8 +634,15 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // ---------------------------------------------------------------------------------------
 template <int MODE, class SC, typename STP>
 __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, const FrameDev& F, int tile, int lane, STP stack) {
-    const int tx = tile % F.tiles_x, ty = F.tile_y0 + tile / F.tiles_x;
+    const int ltr = tile / F.tiles_x, tx = tile - ltr * F.tiles_x;   // ltr: tile row within this launch
+    int ty = F.tile_y0 + ltr;
+    if (F.n_parts > 1) {
+        const int lr = ltr / F.grid_g, sub = ltr - lr * F.grid_g;  // output tile row within this launch, traced row inside it
+        const int blk = lr / F.part_block;
+        ty = ((blk * F.n_parts + F.part) * F.part_block + (lr - blk * F.part_block)) * F.grid_g + sub;
+    }
     const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+    const int y_store = (F.compact ? ltr : ty) * 8 + (lane >> 3);    // row of the traced image as laid out in fb / hit_ids
 
     const f3 p0 = {F.p0[0], F.p0[1], F.p0[2]}, d10 = {F.d10[0], F.d10[1], F.d10[2]}, d20 = {F.d20[0], F.d20[1], F.d20[2]};
     const f3 O = {F.cam[0], F.cam[1], F.cam[2]};
@@ -642,10 +673,10 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
     }
     const uint32_t px = vec_to_pixel(color);
 
-    if (F.hit_ids) F.hit_ids[(size_t)y * F.width + x] = h.tri;
+    if (F.hit_ids) F.hit_ids[(size_t)y_store * F.width + x] = h.tri;
     const int g = F.grid_g;
     if (g == 1) {
-        F.fb[(size_t)y * F.pitch + x] = px;
+        F.fb[(size_t)y_store * F.pitch + x] = px;
     } else {
         // box filter over g x g blocks of QUANTISED pixels, rounded down per channel
         uint32_t ar = ((px >> 24) << 16) | ((px >> 16) & 255u);      // A | R   (16 bits each)
@@ -657,9 +688,15 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
         if (((lane & 7) % g) == 0 && ((lane >> 3) % g) == 0) {
             const uint32_t n = (uint32_t)(g * g);
             const uint32_t out = (((ar >> 16) / n) << 24) | (((ar & 0xffffu) / n) << 16) | (((gb >> 16) / n) << 8) | ((gb & 0xffffu) / n);
-            F.fb[(size_t)(y / g) * F.pitch + (x / g)] = out;
+            F.fb[(size_t)(y_store / g) * F.pitch + (x / g)] = out;
         }
     }
+#ifdef MRT_LOOP_COUNTS
+    for (int i = 0; i < kProfSites; ++i) {
+        const uint32_t a = wave_sum(wd.wave_n[i]), b = wave_sum(wd.lane_n[i]);
+        if (lane == 0 && b) { atomicAdd(&F.counters[kProfBase + 2 * i], (unsigned long long)a); atomicAdd(&F.counters[kProfBase + 2 * i + 1], (unsigned long long)b); }
+    }
+#endif
     if (F.stats) {
         const uint32_t hits = (uint32_t)__popcll(__ballot(h.tri >= 0));
         const uint32_t sh = wave_sum(n_shadow), se = wave_sum(n_secondary);

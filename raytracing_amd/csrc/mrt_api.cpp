@@ -131,8 +131,17 @@ int parse_flags(mrt_ctx* c, uint32_t flags, int& mode, int& g) {
     return MRT_OK;
 }
 
+// tile rows (8 pixel rows each) of share `part`: those R < rows with (R / block) % n_parts == part
+int part_tile_rows(int rows, int part, int n_parts, int block) {
+    const int cycle = block * n_parts;
+    const int full = rows / cycle, rest = rows - full * cycle;
+    return full * block + std::min(block, std::max(0, rest - part * block));
+}
+
+struct RowShare { int part = 0, n_parts = 1, block = 1, compact = 0; };
+
 int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, int y_end, uint32_t* fb_dev,
-                  int pitch_px, int32_t* ids_dev, hipStream_t stream) {
+                  int pitch_px, int32_t* ids_dev, hipStream_t stream, const RowShare* share = nullptr) {
     int mode, g;
     if (int rc = parse_flags(c, flags, mode, g)) return rc;
     if (!c->has_scene) return fail(c, MRT_E_STATE, "mrt_scene_upload has not been called");
@@ -145,6 +154,15 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
     F.grid_g = g;
     F.tile_y0 = y_begin * g / 8;
     F.n_tiles = ((y_end - y_begin) * g / 8) * F.tiles_x;
+    F.n_parts = 1; F.part_block = 1;
+    if (share) {
+        if (share->n_parts < 1 || share->part < 0 || share->part >= share->n_parts || share->block < 1)
+            return fail(c, MRT_E_ARG, "bad share: need 0 <= part < n_parts and block_tile_rows >= 1");
+        F.part = share->part; F.n_parts = share->n_parts; F.part_block = share->block; F.compact = share->compact ? 1 : 0;
+        F.tile_y0 = 0;
+        F.n_tiles = part_tile_rows(c->height / 8, share->part, share->n_parts, share->block) * g * F.tiles_x;
+        if (share->n_parts == 1) F.compact = 0;      // the whole frame: packed and in place coincide
+    }
     F.pitch = pitch_px;
     F.fb = fb_dev;
     F.hit_ids = ids_dev;
@@ -330,6 +348,20 @@ int mrt_render_device(mrt_ctx* c, const float cam[16], uint32_t flags, int y_beg
     return render_common(c, cam, flags, y_begin, y_end, (uint32_t*)fb_dev, pitch_px, (int32_t*)hit_ids_dev, (hipStream_t)stream);
 }
 
+int mrt_render_device_part(mrt_ctx* c, const float cam[16], uint32_t flags, int part, int n_parts, int block_tile_rows,
+                           int compact, void* fb_dev, int pitch_px, void* hit_ids_dev, void* stream) {
+    if (!c) return MRT_E_ARG;
+    MRT_HIP(c, hipSetDevice(c->device));
+    RowShare sh;
+    sh.part = part; sh.n_parts = n_parts; sh.block = block_tile_rows; sh.compact = compact;
+    return render_common(c, cam, flags, 0, c->height, (uint32_t*)fb_dev, pitch_px, (int32_t*)hit_ids_dev, (hipStream_t)stream, &sh);
+}
+
+int mrt_part_rows(int height, int part, int n_parts, int block_tile_rows) {
+    if (height <= 0 || (height % 8) || n_parts < 1 || part < 0 || part >= n_parts || block_tile_rows < 1) return MRT_E_ARG;
+    return 8 * part_tile_rows(height / 8, part, n_parts, block_tile_rows);
+}
+
 int mrt_render(mrt_ctx* c, const float cam[16], uint32_t flags, uint32_t* fb, int pitch_px, int32_t* hit_ids) {
     if (!c) return MRT_E_ARG;
     if (!fb) return fail(c, MRT_E_ARG, "null framebuffer");
@@ -375,6 +407,17 @@ int mrt_get_ray_counts(mrt_ctx* c, uint64_t out[4]) {
     if (wd != 0) return fail(c, MRT_E_LIMIT, "a traversal loop exhausted its iteration budget (code " + std::to_string(wd) + ")");
     return MRT_OK;
 }
+
+#ifdef MRT_LOOP_COUNTS
+// diagnostic build only: out[2*site] = wave-level executions, out[2*site+1] = lane-level executions
+extern "C" int mrt_debug_loop_counts(mrt_ctx* c, uint64_t* out) {
+    if (!c || !out) return MRT_E_ARG;
+    MRT_HIP(c, hipSetDevice(c->device));
+    MRT_HIP(c, hipStreamSynchronize(c->last_stream));
+    MRT_HIP(c, hipMemcpy(out, c->d_counters.p + kProfBase, 2 * kProfSites * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return MRT_OK;
+}
+#endif
 
 int mrt_trace_packets(mrt_ctx* c, int n_packets, const float* O, const float* D, const float* rD, float* t,
                       int32_t* tri, float* u, float* v) {

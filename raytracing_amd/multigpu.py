@@ -6,7 +6,14 @@ is used at a coarser grain: the scene is replicated, rank r renders a contiguous
 8-pixel tile rows (``band_rows``), and the finished bands are sent to rank 0 with one grouped
 send/recv (``gather_bands``; RCCL over xGMI with the "nccl" backend, gloo on CPU for tests).
 No other collective is needed.
+
+Contiguous bands balance badly when the cost of a tile depends on what it shows (sky rows cost
+a fraction of rows full of refracting walls), so the split used for throughput is interleaved:
+tile rows are dealt to the ranks in blocks (``part_row_index``), every rank other than 0 renders
+its share packed into a small buffer and sends that one buffer, and rank 0 -- which renders its own
+share in place -- scatters the received rows to their places (``PartGather``).
 """
+import numpy as np
 
 
 def band_rows(height, world, rank):
@@ -38,3 +45,50 @@ def gather_bands(fb, world, rank, dist):
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+
+
+def part_row_index(height, world, rank, block=1):
+    """Sorted pixel-row indices of rank's interleaved share: the 8-row tile rows R with
+    (R // block) % world == rank.  Matches mrt_render_device_part / mrt_part_rows."""
+    if height % 8:
+        raise ValueError("height must be a multiple of 8")
+    if not (0 <= rank < world) or block < 1:
+        raise ValueError("need 0 <= rank < world and block >= 1")
+    tile_rows = np.arange(height // 8)
+    mine = tile_rows[(tile_rows // block) % world == rank]
+    return (mine[:, None] * 8 + np.arange(8)[None, :]).reshape(-1)
+
+
+class PartGather:
+    """Gathers the interleaved shares of one frame into rank 0's frame tensor.
+
+    Every rank builds one; rank 0 owns a receive buffer per peer and the row indices of every
+    share.  ``gather(frame, packed, dist)``: on rank r > 0 sends ``packed`` (its share, rows
+    packed in increasing order); on rank 0 receives all shares and writes their rows into
+    ``frame`` (H x W), whose own share rank 0 has already rendered in place."""
+
+    def __init__(self, height, width, world, rank, block, torch, device, dtype):
+        self.world, self.rank, self.block, self.torch = world, rank, block, torch
+        self.rows = [part_row_index(height, world, r, block) for r in range(world)]
+        self.n_rows = [len(r) for r in self.rows]
+        self.staging, self.index = {}, {}
+        if rank == 0:
+            for r in range(1, world):
+                if self.n_rows[r]:
+                    self.staging[r] = torch.empty((self.n_rows[r], width), dtype=dtype, device=device)
+                    self.index[r] = torch.from_numpy(self.rows[r].astype(np.int64)).to(device)
+
+    def gather(self, frame, packed, dist):
+        if self.world <= 1:
+            return
+        ops = []
+        if self.rank == 0:
+            ops = [dist.P2POp(dist.irecv, buf, r) for r, buf in self.staging.items()]
+        elif self.n_rows[self.rank]:
+            ops = [dist.P2POp(dist.isend, packed, 0)]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if self.rank == 0:
+            for r, buf in self.staging.items():
+                frame.index_copy_(0, self.index[r], buf)

@@ -214,6 +214,47 @@ def test_row_bands_on_device_equal_full_frame(maze_scene):
     rt.close()
 
 
+@pytest.mark.parametrize("mode,grid", [(MODE_RECURSIVE, 1), (MODE_PACKET, 2)])
+def test_interleaved_shares_on_device_equal_full_frame(maze_scene, mode, grid):
+    """mrt_render_device_part: the shares of an interleaved tile-row split, in place and packed,
+    reassemble to exactly the full frame (hit ids included), also with a sample grid and with a
+    ragged last cycle (33 tile rows)."""
+    import torch
+    from raytracing_amd.multigpu import part_row_index
+    W, H = 256, 264
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(maze_scene)
+    cam = pose_cam(POSES[1])
+    full, full_ids = rt.render(cam, mode=mode, spp_grid=grid)
+    stream = torch.cuda.current_stream().cuda_stream
+    for world, block in ((2, 1), (3, 4), (8, 2), (4, 40)):
+        fb = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
+        ids = torch.full((H * grid, W * grid), -7, dtype=torch.int32, device="cuda:0")
+        for r in range(world):
+            rt.render_device_part(cam, fb.data_ptr(), W, r, world, block, compact=False, mode=mode, spp_grid=grid,
+                                  ids_ptr=ids.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(fb.cpu().numpy().view(np.uint32), full)
+        assert np.array_equal(ids.cpu().numpy(), full_ids)
+        got = np.zeros((H, W), np.uint32)
+        for r in range(world):
+            rows = part_row_index(H, world, r, block)
+            assert rt.L.mrt_part_rows(H, r, world, block) == len(rows)
+            packed = torch.zeros((max(len(rows), 8), W), dtype=torch.int32, device="cuda:0")
+            pids = torch.full((max(len(rows), 8) * grid, W * grid), -7, dtype=torch.int32, device="cuda:0")
+            rt.render_device_part(cam, packed.data_ptr(), W, r, world, block, compact=True, mode=mode, spp_grid=grid,
+                                  ids_ptr=pids.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            got[rows] = packed.cpu().numpy().view(np.uint32)[:len(rows)]
+            if len(rows):
+                id_rows = (rows[:, None] * grid + np.arange(grid)[None, :]).reshape(-1)
+                assert np.array_equal(pids.cpu().numpy()[:len(rows) * grid], full_ids[id_rows])
+        assert np.array_equal(got, full)
+    with pytest.raises(MrtError, match="share"):
+        rt.render_device_part(cam, fb.data_ptr(), W, 2, 2, 1)
+    rt.close()
+
+
 def test_error_paths(maze_scene):
     rt = Raytracer(64, 64, device=0)
     with pytest.raises(MrtError, match="scene_upload"):

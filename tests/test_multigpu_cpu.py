@@ -67,3 +67,67 @@ def test_two_rank_band_gather_equals_full_frame(tmp_path, world, maze_oracle):
     got = np.load(out)
     ref = maze_oracle.render(oracle_lib.lookat((6, 3, 12), (0, 0, 0)), W, H, mode=0, want_ids=False)["fb"]
     assert np.array_equal(got, ref)
+
+
+def test_part_rows_partition_the_frame_and_match_the_library():
+    from raytracing_amd import binding
+    from raytracing_amd.multigpu import part_row_index
+    L = binding.lib()
+    for h in (8, 104, 1080, 4320):
+        for world in (1, 2, 3, 8):
+            for block in (1, 2, 4, 7):
+                shares = [part_row_index(h, world, r, block) for r in range(world)]
+                assert np.array_equal(np.sort(np.concatenate(shares)), np.arange(h))
+                for r, s in enumerate(shares):
+                    assert np.all(np.diff(s) > 0)
+                    assert L.mrt_part_rows(h, r, world, block) == len(s)
+    assert L.mrt_part_rows(601, 0, 2, 1) < 0 and L.mrt_part_rows(64, 2, 2, 1) < 0 and L.mrt_part_rows(64, 0, 2, 0) < 0
+    with pytest.raises(ValueError):
+        part_row_index(64, 2, 2)
+
+
+def _part_worker(rank, world, port, W, H, block, out_path):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib
+    from raytracing_amd import scene_io
+    from raytracing_amd.multigpu import PartGather
+    scene = scene_io.load_scene(os.path.join(HERE, "golden", "maze.mrts"))
+    o = oracle_lib.Oracle()
+    o.add_scene(scene)
+    o.build_bvh()
+    cam = oracle_lib.lookat((6, 3, 12), (0, 0, 0))
+    pg = PartGather(H, W, world, rank, block, torch, "cpu", torch.int32)
+    mine = pg.rows[rank]
+    # each rank traces only the tile rows of its share (one oracle call per run of consecutive rows)
+    frame = torch.zeros((H, W), dtype=torch.int32)
+    tile_rows = np.unique(mine // 8)
+    for tr in tile_rows:
+        part = o.render(cam, W, H, mode=0, rows=(int(tr) * 8, int(tr) * 8 + 8), want_ids=False)["fb"]
+        frame[tr * 8:tr * 8 + 8] = torch.from_numpy(part[tr * 8:tr * 8 + 8].view(np.int32))
+    packed = frame[torch.from_numpy(mine.astype(np.int64))].contiguous() if len(mine) else torch.zeros((0, W), dtype=torch.int32)
+    if rank != 0:
+        frame.zero_()                      # only the packed buffer travels
+    pg.gather(frame, packed, dist)
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, frame.numpy().view(np.uint32))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,block", [(2, 1), (3, 2), (2, 20)])
+def test_interleaved_share_gather_equals_full_frame(tmp_path, world, block, maze_oracle):
+    import oracle_lib
+    W, H = 160, 104          # 13 tile rows: ragged last cycle; block 20 leaves rank 1 with nothing
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "fb.npy")
+    mp.spawn(_part_worker, args=(world, port, W, H, block, out), nprocs=world, join=True)
+    got = np.load(out)
+    ref = maze_oracle.render(oracle_lib.lookat((6, 3, 12), (0, 0, 0)), W, H, mode=0, want_ids=False)["fb"]
+    assert np.array_equal(got, ref)
