@@ -69,6 +69,7 @@ struct Watch {
 // node / triangle arrays.  Indices are in units of the array element.
 // ---------------------------------------------------------------------------------------
 struct SceneGlobal {
+    static constexpr bool kPrefetchLeaf = false;
     const v4f* nodes; const v4f* triA; const v4f* triB; const v2f* triC;
     __device__ __forceinline__ v4f node(uint32_t i) const { return nodes[i]; }
     __device__ __forceinline__ v4f tri_a(uint32_t k) const { return triA[k]; }
@@ -78,6 +79,7 @@ struct SceneGlobal {
     __device__ __forceinline__ uint32_t node_count(uint32_t n) const { return __float_as_uint(reinterpret_cast<const float*>(nodes)[8 * n + 7]); }
 };
 struct SceneLds {
+    static constexpr bool kPrefetchLeaf = true;     // request triangle k+1 before testing triangle k
     MRT_LDS const v4f* nodes; MRT_LDS const v4f* triA; MRT_LDS const v4f* triB; MRT_LDS const v2f* triC;
     __device__ __forceinline__ v4f node(uint32_t i) const { return nodes[i]; }
     __device__ __forceinline__ v4f tri_a(uint32_t k) const { return triA[k]; }
@@ -264,18 +266,25 @@ __device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, 
             if (wd.expired(2)) break;
             if (count != 0) {
                 if (lane >= i) {
-                    // the next triangle's record is requested before the current one is tested
-                    v4f A = sc.tri_a(first), B = sc.tri_b(first);
-                    v2f C = sc.tri_c(first);
-                    const uint32_t last = first + count - 1;
-                    for (uint32_t k = first; k <= last; ++k) {
-                        if (wd.expired(64)) break;
-                        MRT_TICK(wd, 10);
-                        const uint32_t kn = k < last ? k + 1 : k;
-                        const v4f An = sc.tri_a(kn), Bn = sc.tri_b(kn);
-                        const v2f Cn = sc.tri_c(kn);
-                        tri_test<true>(A, B, C, O, D, t, h, wd);
-                        A = An; B = Bn; C = Cn;
+                    if constexpr (SC::kPrefetchLeaf) {
+                        v4f A = sc.tri_a(first), B = sc.tri_b(first);
+                        v2f C = sc.tri_c(first);
+                        const uint32_t last = first + count - 1;
+                        for (uint32_t k = first; k <= last; ++k) {
+                            if (wd.expired(64)) break;
+                            MRT_TICK(wd, 10);
+                            const uint32_t kn = k < last ? k + 1 : k;
+                            const v4f An = sc.tri_a(kn), Bn = sc.tri_b(kn);
+                            const v2f Cn = sc.tri_c(kn);
+                            tri_test<true>(A, B, C, O, D, t, h, wd);
+                            A = An; B = Bn; C = Cn;
+                        }
+                    } else {
+                        for (uint32_t k = first; k < first + count; ++k) {
+                            if (wd.expired(64)) break;
+                            MRT_TICK(wd, 10);
+                            tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
+                        }
                     }
                 }
                 break;
@@ -400,18 +409,27 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
         const uint32_t first = sc.node_first(node), count = sc.node_count(node);
         if (count != 0) {
             if ((m >> lane) & 1ull) {
-                v4f A = sc.tri_a(first), B = sc.tri_b(first);
-                v2f C = sc.tri_c(first);
-                const uint32_t last = first + count - 1;
-                for (uint32_t k = first; k <= last; ++k) {
-                    if (wd.expired(256)) break;
-                    MRT_TICK(wd, 5);
-                    const uint32_t kn = k < last ? k + 1 : k;
-                    const v4f An = sc.tri_a(kn), Bn = sc.tri_b(kn);
-                    const v2f Cn = sc.tri_c(kn);
-                    if (h.tri < 0) tri_test<true>(A, B, C, O, D, t, h, wd);
-                    if (!__any(h.tri < 0)) break;
-                    A = An; B = Bn; C = Cn;
+                if constexpr (SC::kPrefetchLeaf) {
+                    v4f A = sc.tri_a(first), B = sc.tri_b(first);
+                    v2f C = sc.tri_c(first);
+                    const uint32_t last = first + count - 1;
+                    for (uint32_t k = first; k <= last; ++k) {
+                        if (wd.expired(256)) break;
+                        MRT_TICK(wd, 5);
+                        const uint32_t kn = k < last ? k + 1 : k;
+                        const v4f An = sc.tri_a(kn), Bn = sc.tri_b(kn);
+                        const v2f Cn = sc.tri_c(kn);
+                        if (h.tri < 0) tri_test<true>(A, B, C, O, D, t, h, wd);
+                        if (!__any(h.tri < 0)) break;
+                        A = An; B = Bn; C = Cn;
+                    }
+                } else {
+                    for (uint32_t k = first; k < first + count; ++k) {
+                        if (wd.expired(256)) break;
+                        MRT_TICK(wd, 5);
+                        if (h.tri < 0) tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
+                        if (!__any(h.tri < 0)) break;
+                    }
                 }
             }
             found = __ballot(h.tri >= 0);

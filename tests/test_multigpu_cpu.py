@@ -131,3 +131,80 @@ def test_interleaved_share_gather_equals_full_frame(tmp_path, world, block, maze
     got = np.load(out)
     ref = maze_oracle.render(oracle_lib.lookat((6, 3, 12), (0, 0, 0)), W, H, mode=0, want_ids=False)["fb"]
     assert np.array_equal(got, ref)
+
+
+class _OracleRenderer:
+    """Stand-in for binding.Raytracer in the CPU test of bench.Workload's multi-rank logic: writes
+    frames the oracle traced through the same raw-pointer calls."""
+
+    def __init__(self, frame):
+        self.frame = np.ascontiguousarray(frame)
+        self.calls = 0
+
+    def _put(self, ptr, rows):
+        import ctypes
+        a = np.ascontiguousarray(rows)
+        ctypes.memmove(ptr, a.ctypes.data, a.nbytes)
+
+    def render_device(self, cam, fb_ptr, pitch, mode=0, spp_grid=1, rows=None, ids_ptr=None, stream=None):
+        self.calls += 1
+        self._put(fb_ptr, self.frame)
+
+    def render_device_part(self, cam, fb_ptr, pitch, part, n_parts, block_tile_rows=1, compact=False, mode=0, spp_grid=1,
+                           ids_ptr=None, stream=None):
+        from raytracing_amd.multigpu import part_row_index
+        self.calls += 1
+        rows = part_row_index(self.frame.shape[0], n_parts, part, block_tile_rows)
+        if compact:
+            self._put(fb_ptr, self.frame[rows])
+        else:
+            W = self.frame.shape[1]
+            for y in rows:
+                self._put(fb_ptr + int(y) * W * 4, self.frame[y])
+
+    def ray_counts(self):
+        return {"primary": 10, "shadow": 5, "secondary": 1, "primary_hits": 5}
+
+
+def _bench_worker(rank, world, port, W, H, split, out_path):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    import oracle_lib
+    from raytracing_amd import scene_io
+    o = oracle_lib.Oracle()
+    o.add_scene(scene_io.load_scene(os.path.join(HERE, "golden", "maze.mrts")))
+    o.build_bvh()
+    frame = o.render(oracle_lib.lookat((6, 3, 12), (0, 0, 0)), W, H, mode=0, want_ids=False)["fb"].view(np.int32)
+    wl = bench.Workload("t", None, W, H, 0, 1, None, rank, world, torch, dist, split=split, rt=_OracleRenderer(frame), device="cpu")
+    res = wl.run(3, 1)
+    assert wl.rt.calls == 4
+    assert res["rays_per_step"] == 16 * world
+    if rank == 0:
+        if split == "frames":
+            got = wl.frames.numpy().view(np.uint32)              # [world, H, W]: every rank's frame arrived
+        else:
+            got = wl.frame()[None]
+        np.save(out_path, got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,split", [(2, "frames"), (3, "rows"), (2, "rows")])
+def test_bench_workload_multi_rank_logic(tmp_path, world, split, maze_oracle):
+    """bench.py's step loop (double-buffered frames, deferred waits, share scatter) under gloo."""
+    import oracle_lib
+    W, H = 160, 104
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "fb.npy")
+    mp.spawn(_bench_worker, args=(world, port, W, H, split, out), nprocs=world, join=True)
+    got = np.load(out)
+    ref = maze_oracle.render(oracle_lib.lookat((6, 3, 12), (0, 0, 0)), W, H, mode=0, want_ids=False)["fb"]
+    for f in got:
+        assert np.array_equal(f, ref)
