@@ -261,6 +261,15 @@ def main():
                                "algorithmic_flops_per_launch": int(flops),
                                "hbm": {"algorithmic_bytes_per_launch": 4 * W * H, "achieved_GBps": round(4 * W * H / (res["kernel_ms"] * 1e-3) / 1e9, 2), "peak_GBps": 8000}}
 
+    if rank == 0 and world == 1:
+        fbh = np.zeros((H, W), np.uint32)
+        head.rt.render(cam, mode=MODE_RECURSIVE, want_ids=False, fb=fbh)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            head.rt.render(cam, mode=MODE_RECURSIVE, want_ids=False, fb=fbh)
+        out["host_framebuffer"] = {"ms_per_frame": round((time.perf_counter() - t0) / 10 * 1e3, 4),
+                                   "what": "the same frame through the synchronous mrt_render: kernel, device-to-host copy over "
+                                           "PCIe into pinned staging, copy into the caller's buffer (never `value`)"}
     if not args.no_extra:
         c4 = Workload("c4", scene, 7680, 4320, MODE_PACKET, 4, cam, rank, world, torch, dist, split="rows")
         r4 = c4.run(max(2, min(args.steps, 5)), 1)

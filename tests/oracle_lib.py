@@ -188,6 +188,21 @@ class Oracle:
             out["counters"] = dict(zip(COUNTER_NAMES, (int(x) for x in ctr)))
         return out
 
+    def render_band(self, cam, W, H, y0, y1, mode=0, spp_grid=1):
+        """Rows [y0, y1) of the frame only, without allocating the whole frame (full-size configurations):
+        returns the band's pixels (y1-y0, W) and hit ids ((y1-y0)*g, W*g)."""
+        cam = np.ascontiguousarray(cam, np.float32).reshape(16)
+        g = max(1, spp_grid)
+        fb = np.zeros((y1 - y0, W), np.uint32)
+        ids = np.full(((y1 - y0) * g, W * g), -2, np.int32)
+        # the library indexes both arrays by frame row; hand it the address frame row 0 would have
+        fb0 = C.c_void_p(fb.ctypes.data - y0 * W * 4)
+        ids0 = C.c_void_p(ids.ctypes.data - y0 * g * W * g * 4)
+        rc = self.L.ora_render(self.h, _p(cam), W, H, mode, spp_grid, y0, y1, fb0, W, ids0, None, None)
+        if rc != 0:
+            raise RuntimeError("ora_render failed")
+        return fb, ids
+
     def trace_ray(self, O, D, tmax=1e8, kind=0):
         t = C.c_float()
         uv = np.zeros(2, np.float32)

@@ -255,6 +255,71 @@ def test_interleaved_shares_on_device_equal_full_frame(maze_scene, mode, grid):
     rt.close()
 
 
+def test_8k_16spp_frame_rows_match_oracle(maze_scene, maze_oracle):
+    """The multi-GPU configuration at its full size (7680x4320, 4x4 sample grid = 530,841,600 primary
+    rays): the whole frame is rendered once, and four 8-row strips of it -- first, last, and two through
+    the middle of the scene -- are checked against the oracle, pixels and hit ids of all 16 samples."""
+    import torch
+    W, H, g = 7680, 4320, 4
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(maze_scene)
+    cam = oracle_lib.IDENTITY
+    stream = torch.cuda.current_stream().cuda_stream
+    fb = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
+    rt.render_device(cam, fb.data_ptr(), W, mode=MODE_PACKET, spp_grid=g, stream=stream)
+    torch.cuda.synchronize()
+    counts = rt.ray_counts()
+    assert counts["primary"] == W * H * g * g and counts["shadow"] == counts["primary_hits"]
+    n_rows = H // 8
+    strip = torch.zeros((8, W), dtype=torch.int32, device="cuda:0")
+    ids = torch.zeros((8 * g, W * g), dtype=torch.int32, device="cuda:0")
+    for R in (0, 231, 300, n_rows - 1):
+        ref_fb, ref_ids = maze_oracle.render_band(cam, W, H, 8 * R, 8 * R + 8, mode=MODE_PACKET, spp_grid=g)
+        assert np.array_equal(fb[8 * R:8 * R + 8].cpu().numpy().view(np.uint32), ref_fb), "tile row %d" % R
+        # the same strip as a packed share (one tile row per share), with the hit ids of its samples
+        rt.render_device_part(cam, strip.data_ptr(), W, R, n_rows, 1, compact=True, mode=MODE_PACKET, spp_grid=g,
+                              ids_ptr=ids.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(strip.cpu().numpy().view(np.uint32), ref_fb)
+        assert np.array_equal(ids.cpu().numpy(), ref_ids)
+    rt.close()
+
+
+def test_million_triangle_scene_4k_rows_match_oracle():
+    """The large-scene configuration at its full size: 1,000,000-triangle soup, 3840x2160, scene in
+    global memory.  BVH arrays identical to the oracle's; strips of the packet frame and of the
+    recursive frame (hit ids and pixels) equal the oracle's."""
+    import torch
+    W, H = 3840, 2160
+    scene = scene_io.soup_scene(1000000)
+    ora = oracle_lib.Oracle()
+    ora.add_scene(scene)
+    ora.build_bvh()
+    mm, fc, idx = ora.bvh_arrays()
+    mine = binding.bvh_build_host(scene)
+    n = ora.bvh_info["poolPtr"] + 1
+    assert mine["poolPtr"] == ora.bvh_info["poolPtr"] and mine["maxDepth"] == ora.bvh_info["maxDepth"]
+    assert np.array_equal(idx, mine["tri_idx"])
+    assert np.array_equal(fc[3:], mine["node_first_cnt"][3:n])          # slots 1 and 2 are never written
+    assert np.array_equal(bits(mm)[3:], bits(mine["node_minmax"][3:n]))
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(scene)
+    cam = oracle_lib.IDENTITY
+    stream = torch.cuda.current_stream().cuda_stream
+    n_rows = H // 8
+    strip = torch.zeros((8, W), dtype=torch.int32, device="cuda:0")
+    ids = torch.zeros((8, W), dtype=torch.int32, device="cuda:0")
+    for mode in (MODE_PACKET, MODE_RECURSIVE):
+        for R in (3, 135, 200, n_rows - 2):
+            ref_fb, ref_ids = ora.render_band(cam, W, H, 8 * R, 8 * R + 8, mode=mode)
+            rt.render_device_part(cam, strip.data_ptr(), W, R, n_rows, 1, compact=True, mode=mode,
+                                  ids_ptr=ids.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(ids.cpu().numpy(), ref_ids), "mode %d tile row %d" % (mode, R)
+            assert colour_mismatch_fraction(strip.cpu().numpy().view(np.uint32), ref_fb) <= 0.001
+    rt.close()
+
+
 def test_error_paths(maze_scene):
     rt = Raytracer(64, 64, device=0)
     with pytest.raises(MrtError, match="scene_upload"):
