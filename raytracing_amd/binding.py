@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmrt.so")
+LIB_PATH = os.environ.get("MRT_LIB") or os.path.join(_HERE, "libmrt.so")     # MRT_LIB: tuning builds only
 
 MODE_PACKET = 0
 MODE_RECURSIVE = 1

@@ -39,9 +39,12 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct Hit { int tri; float u, v; };
 
-// Loop budget shared by every traversal loop of one tile.  No correct traversal comes near it
-// (it is sized from the node and triangle counts); if a loop ever exhausts it, the loop ends,
-// a code is left in counters[5] for the host to report, and the kernel still terminates.
+// Loop budget shared by the outer traversal loops of one tile (work-list loops, the per-lane
+// traversal's outer loop, shading rounds).  No correct traversal comes near it (it is sized from
+// the node and triangle counts); if a loop ever exhausts it, the loop ends, a code is left in
+// counters[5] for the host to report, and the kernel still terminates.  The innermost loops are
+// not charged: a leaf's triangle loop is bounded by its count and a descent by the depth of the
+// tree, which the library builds itself, and a check there costs 10-17 % of the frame time.
 struct Watch {
     int left;
     unsigned long long* flag;
@@ -186,15 +189,24 @@ __device__ __forceinline__ void tri_test(v4f A, v4f B, v2f C, f3 O, f3 D, float&
         if (!__any(!clear_miss)) return;
     }
     MRT_TICK(wd, WAVE_REJECT ? 7 : 13);
-    if (det < -kEpsilon) return;
+    // The reference's chain of early returns with wave-uniform branches: `live` carries each lane's
+    // own outcome, a stage is skipped only when no lane is left, and the running hit is updated by
+    // selects at one place.
+    bool live = !(det < -kEpsilon);
+    if (!__any(live)) return;
     const float invDet = 1 / det;
     const float u = un * invDet;
-    if (u < 0 || u > 1) return;
+    live = live && !(u < 0 || u > 1);
+    if (!__any(live)) return;
     const float v = vn * invDet;
-    if (v < 0 || u + v > 1) return;
+    live = live && !(v < 0 || u + v > 1);
+    if (!__any(live)) return;
     const float T = tn * invDet;
-    if (T < 0.0f) return;
-    if (T < t) { t = T; h.tri = (int)__float_as_uint(C.y); h.u = u; h.v = v; }
+    live = live && !(T < 0.0f) && (T < t);
+    t = live ? T : t;
+    h.tri = live ? (int)__float_as_uint(C.y) : h.tri;
+    h.u = live ? u : h.u;
+    h.v = live ? v : h.v;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -263,7 +275,6 @@ __device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, 
         int i = __ffsll((long long)mask) - 1;
         uint32_t first = wbits(n0), count = wbits(n1);
         for (;;) {                             // visit(node = {first,count}, firstActive = i)
-            if (wd.expired(2)) break;
             if (count != 0) {
                 if (lane >= i) {
                     if constexpr (SC::kPrefetchLeaf) {
@@ -271,7 +282,6 @@ __device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, 
                         v2f C = sc.tri_c(first);
                         const uint32_t last = first + count - 1;
                         for (uint32_t k = first; k <= last; ++k) {
-                            if (wd.expired(64)) break;
                             MRT_TICK(wd, 10);
                             const uint32_t kn = k < last ? k + 1 : k;
                             const v4f An = sc.tri_a(kn), Bn = sc.tri_b(kn);
@@ -281,7 +291,6 @@ __device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, 
                         }
                     } else {
                         for (uint32_t k = first; k < first + count; ++k) {
-                            if (wd.expired(64)) break;
                             MRT_TICK(wd, 10);
                             tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
                         }
@@ -332,7 +341,6 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
     while (alive) {
         if (wd.expired(4)) break;
         while (alive && count == 0) {
-            if (wd.expired(8)) { alive = false; break; }
             MRT_TICK(wd, 0);
             const uint32_t L = first, Rr = first + 1;
             const v4f l0 = sc.node(2 * L), l1 = sc.node(2 * L + 1), r0 = sc.node(2 * Rr), r1 = sc.node(2 * Rr + 1);
@@ -358,7 +366,6 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
         }
         if (alive) {
             for (uint32_t k = first; k < first + count; ++k) {
-                if (wd.expired(128)) break;
                 MRT_TICK(wd, 1);
                 tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
             }
@@ -414,7 +421,6 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
                     v2f C = sc.tri_c(first);
                     const uint32_t last = first + count - 1;
                     for (uint32_t k = first; k <= last; ++k) {
-                        if (wd.expired(256)) break;
                         MRT_TICK(wd, 5);
                         const uint32_t kn = k < last ? k + 1 : k;
                         const v4f An = sc.tri_a(kn), Bn = sc.tri_b(kn);
@@ -425,7 +431,6 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
                     }
                 } else {
                     for (uint32_t k = first; k < first + count; ++k) {
-                        if (wd.expired(256)) break;
                         MRT_TICK(wd, 5);
                         if (h.tri < 0) tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
                         if (!__any(h.tri < 0)) break;

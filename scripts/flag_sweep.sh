@@ -1,0 +1,33 @@
+#!/bin/bash
+# Builds libmrt variants with extra compiler flags for kernels.hip (CPU side, here) so that one GPU call
+# can time them all:  bash scripts/flag_sweep.sh build ; then on the GPU:  bash scripts/flag_sweep.sh run
+# A tuning aid; variants are written to raytracing_amd/variants/ (git-ignored).
+set -u
+cd "$(dirname "$0")/.."
+CS=raytracing_amd/csrc
+OUT=raytracing_amd/variants
+BASE="-std=c++17 -O3 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -w"
+declare -A V
+V[base]=""
+V[O2]="-O2"
+V[nounroll]="-fno-unroll-loops"
+V[maxilp]="-mllvm -amdgpu-sched-strategy=max-ilp"
+V[maxmem]="-mllvm -amdgpu-sched-strategy=max-memory-clause"
+V[noicm]="-mllvm -disable-licm-promotion"
+V[nojt]="-mllvm -jump-threading-threshold=0"
+if [ "${1:-}" = build ]; then
+  mkdir -p $OUT
+  make -C $CS -j8 >/dev/null
+  for n in "${!V[@]}"; do
+    ( /opt/rocm/bin/hipcc $BASE ${V[$n]} -c $CS/kernels.hip -o $OUT/kernels_$n.o 2>$OUT/$n.log &&
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/libmrt_$n.so $OUT/kernels_$n.o $CS/build/raster.o $CS/build/mrt_api.o $CS/build/bvh_builder.o $CS/build/camera.o &&
+      echo "built $n" || echo "FAILED $n: $(tail -2 $OUT/$n.log)" ) &
+  done
+  wait
+else
+  for f in $OUT/libmrt_*.so; do
+    n=$(basename $f .so); n=${n#libmrt_}
+    echo "== $n"
+    MRT_LIB=$f timeout -k 10 100 python3 -u scripts/perf_probe.py ${PROBE_ARGS:-} 2>&1 | grep -v amdgpu.ids || exit 1
+  done
+fi
