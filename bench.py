@@ -89,6 +89,15 @@ class Workload:
 
     scatter_to = None
 
+    def _render(self, fb, stream_h):
+        if self.gpu and stream_h is None:
+            stream_h = self.torch.cuda.current_stream().cuda_stream
+        if self.world == 1 or self.split == "frames":
+            self.rt.render_device(self.cam, fb.data_ptr(), self.W, mode=self.mode, spp_grid=self.grid, stream=stream_h)
+        else:
+            self.rt.render_device_part(self.cam, fb.data_ptr(), self.W, self.rank, self.world, 1, compact=self.rank != 0,
+                                       mode=self.mode, spp_grid=self.grid, stream=stream_h)
+
     def step(self, timed=False):
         torch, dist = self.torch, self.dist
         stream = torch.cuda.current_stream() if self.gpu else None
@@ -99,11 +108,7 @@ class Workload:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-        if self.world == 1 or self.split == "frames":
-            self.rt.render_device(self.cam, fb.data_ptr(), self.W, mode=self.mode, spp_grid=self.grid, stream=stream_h)
-        else:
-            self.rt.render_device_part(self.cam, fb.data_ptr(), self.W, self.rank, self.world, 1, compact=self.rank != 0,
-                                       mode=self.mode, spp_grid=self.grid, stream=stream_h)
+        self._render(fb, stream_h)
         if timed:
             e1.record(stream)
             self.events.append((e0, e1))
@@ -125,8 +130,16 @@ class Workload:
         if ops:
             self.pending = dist.batch_isend_irecv(ops)
 
-    def run(self, steps, warmup):
+    def run(self, steps, warmup, ramp_s=0.3):
         torch, dist = self.torch, self.dist
+        # the GPU drops to idle clocks while the host builds scenes or runs the CPU baseline and needs
+        # tens of milliseconds of work to come back; spend ramp_s of untimed frames before the warm-up
+        # (render only, no exchange: ranks may need different numbers of frames)
+        t_ramp = time.perf_counter()
+        while self.gpu and time.perf_counter() - t_ramp < ramp_s:
+            for _ in range(4):
+                self._render(self.fb[0], None)
+            torch.cuda.synchronize()
         for _ in range(warmup):
             self.step()
         self._finish_pending()
