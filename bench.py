@@ -43,9 +43,10 @@ sys.path.insert(0, ROOT)
 
 FLOPS_SLAB, FLOPS_TRI = 25, 59              # per test, from the reference source
 FLOPS_FIXED_PRIMARY, FLOPS_FIXED_SECONDARY = 40, 30
-VALU_PEAK_TFLOPS = 157.3                    # fp32 vector peak of the part: packed FMA, 2 flops x 2 lanes per issue slot
-VALU_UNFUSED_TOPS = 157.3 / 4               # 256 CUs x 64 lanes x 2.4 GHz: one unfused, unpacked fp32 operation per lane and clock,
-                                            # the most this path can issue (bit-exact parity forbids contracting a*b+c into an FMA)
+VALU_PEAK_TFLOPS = 157.3                    # fp32 vector peak of the part; counts every lane-operation as a fused multiply-add
+VALU_UNFUSED_TOPS = 157.3 / 2               # the same issue rate with ONE flop per lane-operation (256 CUs x 128 lanes/clk x 2.4 GHz):
+                                            # what unfused arithmetic can reach -- bit-exact parity forbids contracting a*b+c into an
+                                            # FMA; scripts/valu_rate.hip measures 62-72 Tops/s of plain v_mul/v_add on the part
 
 
 class Workload:

@@ -40,10 +40,11 @@ def main():
     summary = {k: {c: {"launches": v[1], "per_launch": v[0] / v[1]} for c, v in sorted(cs.items())} for k, cs in sorted(agg.items())}
     h = summary.get(HEADLINE, {})
     if "SQ_INSTS_VALU" in h and "GRBM_GUI_ACTIVE" in h:
-        # a wave64 VALU instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs
+        # 157.3 Tflop/s of fp32 FMAs = 256 CUs x 128 lanes per clock, so a SIMD retires one wave64 VALU instruction every
+        # 2 clocks; GRBM_GUI_ACTIVE sums the 8 XCDs
         cycles = h["GRBM_GUI_ACTIVE"]["per_launch"] / 8
         summary["_derived"] = {"headline_kernel": HEADLINE, "gpu_cycles_per_launch": cycles,
-                               "valu_issue_utilisation": h["SQ_INSTS_VALU"]["per_launch"] * 4 / (1024 * cycles)}
+                               "valu_issue_utilisation": h["SQ_INSTS_VALU"]["per_launch"] * 2 / (1024 * cycles)}
     json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
     if "FETCH_SIZE" in h and "WRITE_SIZE" in h:
         fk, wk = h["FETCH_SIZE"]["per_launch"], h["WRITE_SIZE"]["per_launch"]

@@ -740,7 +740,13 @@ __device__ __forceinline__ SceneGlobal global_scene(const SceneDev& S) {
 
 // Scene in global memory: one 64-thread workgroup (one wave) per tile.  SD = stack entries.
 template <int MODE, int SD>
-__global__ __launch_bounds__(64, MODE == 0 ? 8 : 4) void render_tiles_global(SceneDev S, FrameDev F) {
+#ifndef MRT_PACKET_WAVES
+#define MRT_PACKET_WAVES 8      // waves per SIMD the packet kernel is compiled for (register budget 512 / n)
+#endif
+#ifndef MRT_RECURSIVE_WAVES
+#define MRT_RECURSIVE_WAVES 4
+#endif
+__global__ __launch_bounds__(64, MODE == 0 ? MRT_PACKET_WAVES : MRT_RECURSIVE_WAVES) void render_tiles_global(SceneDev S, FrameDev F) {
     __shared__ uint32_t lds_stack[MODE == 0 ? 64 : SD * 64];      // only the single-ray traversal keeps a per-lane stack
     const int lane = threadIdx.x;
     const int tile = blockIdx.x;

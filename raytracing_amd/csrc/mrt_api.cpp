@@ -170,7 +170,12 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
     F.stack_entries = c->stack_entries;
     F.stats = getenv("MRT_NO_STATS") ? 0 : 1;
     MRT_HIP(c, hipMemsetAsync(c->d_counters.p, 0, kCounterSlots * sizeof(unsigned long long), stream));
-    MRT_HIP(c, launch_render(c->scene, F, mode, c->resident, c->n_cus, stream));
+    // The LDS-resident kernel pays off for the recursive shader, whose per-lane traversal reads a
+    // different node or triangle in every lane.  The packet path reads wave-uniform data (scalar
+    // loads through the scalar cache) and runs faster with one wave per tile at 8 waves per SIMD.
+    bool resident = c->resident && mode == (int)MRT_MODE_RECURSIVE;
+    if (const char* e = getenv("MRT_RESIDENT_PACKET")) resident = c->resident && atoi(e) != 0;   // tuning aid
+    MRT_HIP(c, launch_render(c->scene, F, mode, resident, c->n_cus, stream));
     c->last_stream = stream;
     return MRT_OK;
 }

@@ -8,13 +8,9 @@ CS=raytracing_amd/csrc
 OUT=raytracing_amd/variants
 BASE="-std=c++17 -O3 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -w"
 declare -A V
-V[base]=""
-V[O2]="-O2"
-V[nounroll]="-fno-unroll-loops"
-V[maxilp]="-mllvm -amdgpu-sched-strategy=max-ilp"
-V[maxmem]="-mllvm -amdgpu-sched-strategy=max-memory-clause"
-V[noicm]="-mllvm -disable-licm-promotion"
-V[nojt]="-mllvm -jump-threading-threshold=0"
+V[r4]=""
+V[r5]="-DMRT_RECURSIVE_WAVES=5"
+V[r6]="-DMRT_RECURSIVE_WAVES=6"
 if [ "${1:-}" = build ]; then
   mkdir -p $OUT
   make -C $CS -j8 >/dev/null

@@ -20,10 +20,14 @@ def main():
     ap.add_argument("--pose", default="P0")
     ap.add_argument("--only", default="", help="packet|recursive")
     ap.add_argument("--lights", default="", help="0|1: only this light count")
+    ap.add_argument("--opaque", action="store_true", help="set refl = refr = 0 on every mesh (primary and shadow rays only)")
     args = ap.parse_args()
     import torch
     from raytracing_amd import Camera, Raytracer, scene_io
     scene = scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "maze.mrts"))
+    if args.opaque:
+        for m in scene["meshes"]:
+            m["refl"], m["refr"] = 0.0, 0.0
     cam = Camera()
     if args.pose == "P1":
         cam.set_position((6, 3, 12))
