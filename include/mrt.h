@@ -106,6 +106,14 @@ int mrt_bvh_build_host(const mrt_mesh* meshes, int n_meshes,
 int mrt_render(mrt_ctx* ctx, const float cam_to_world[16], uint32_t flags,
                uint32_t* fb, int pitch_px, int32_t* hit_ids);
 
+/* Optional: page-locked host memory for the caller's Surface (the reference allocates its pixel
+ * buffer with a 64-byte aligned malloc, surface.cpp:114-120 / template.cpp:98).  mrt_render
+ * recognises a framebuffer that lies in such memory and lets the GPU write the frame straight
+ * into it; any other host pointer goes through an internal page-locked staging buffer and one
+ * extra memcpy.  Returns NULL when no GPU is present or memory is short. */
+void* mrt_host_alloc(size_t bytes);
+void mrt_host_free(void* p);
+
 /* Same frame, device-resident and asynchronous: renders tile rows [y_begin, y_end) (multiples
  * of 8) into DEVICE memory fb_dev (row y at fb_dev + y*pitch_px) on `stream` (a hipStream_t,
  * NULL = the default stream) and returns without synchronising.  This is the launch the

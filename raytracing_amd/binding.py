@@ -18,7 +18,7 @@ MODE_PACKET = 0
 MODE_RECURSIVE = 1
 
 SYMBOLS = ("mrt_create", "mrt_destroy", "mrt_last_error", "mrt_version", "mrt_scene_upload", "mrt_set_lights",
-           "mrt_bvh_build_host", "mrt_render", "mrt_render_device", "mrt_render_device_part", "mrt_part_rows",
+           "mrt_bvh_build_host", "mrt_render", "mrt_host_alloc", "mrt_host_free", "mrt_render_device", "mrt_render_device_part", "mrt_part_rows",
            "mrt_raster_render", "mrt_trace_packets",
            "mrt_trace_rays", "mrt_get_ray_counts", "mrt_camera_look_at")
 
@@ -75,6 +75,10 @@ def lib():
         L.mrt_bvh_build_host.argtypes = [C.POINTER(_Mesh), i32, vp, vp, vp, vp]
         L.mrt_render.argtypes = [vp, vp, C.c_uint32, vp, i32, vp]
         L.mrt_render_device.argtypes = [vp, vp, C.c_uint32, i32, i32, vp, i32, vp, vp]
+        L.mrt_host_alloc.argtypes = [C.c_size_t]
+        L.mrt_host_alloc.restype = vp
+        L.mrt_host_free.argtypes = [vp]
+        L.mrt_host_free.restype = None
         L.mrt_render_device_part.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, i32, vp, i32, vp, vp]
         L.mrt_part_rows.argtypes = [i32, i32, i32, i32]
         L.mrt_raster_render.argtypes = [vp, vp, vp, i32, vp, vp]
@@ -85,6 +89,26 @@ def lib():
         L.mrt_camera_look_at.restype = None
         _lib = L
     return _lib
+
+
+class HostFrame:
+    """A (height, width) uint32 frame in page-locked memory (mrt_host_alloc): mrt_render writes it directly."""
+
+    def __init__(self, height, width):
+        self.L = lib()
+        self.ptr = self.L.mrt_host_alloc(height * width * 4)
+        if not self.ptr:
+            raise MrtError("mrt_host_alloc failed (no GPU, or out of page-locked memory)")
+        self.array = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_uint32)), shape=(height, width))
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self.L.mrt_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.close()
 
 
 def _p(a):

@@ -353,6 +353,16 @@ int mrt_render_device(mrt_ctx* c, const float cam[16], uint32_t flags, int y_beg
     return render_common(c, cam, flags, y_begin, y_end, (uint32_t*)fb_dev, pitch_px, (int32_t*)hit_ids_dev, (hipStream_t)stream);
 }
 
+void* mrt_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void mrt_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int mrt_render_device_part(mrt_ctx* c, const float cam[16], uint32_t flags, int part, int n_parts, int block_tile_rows,
                            int compact, void* fb_dev, int pitch_px, void* hit_ids_dev, void* stream) {
     if (!c) return MRT_E_ARG;
@@ -378,7 +388,14 @@ int mrt_render(mrt_ctx* c, const float cam[16], uint32_t flags, uint32_t* fb, in
     if (hit_ids) MRT_HIP(c, c->d_ids.ensure(npx * g * g));
     if (int rc = render_common(c, cam, flags, 0, c->height, c->d_fb.p, c->width, hit_ids ? c->d_ids.p : nullptr, c->stream))
         return rc;
-    const size_t fb_bytes = npx * 4, id_bytes = hit_ids ? npx * g * g * sizeof(int32_t) : 0, need = fb_bytes + id_bytes + 64;
+    // a framebuffer in page-locked memory (mrt_host_alloc, or registered by the caller) is written directly
+    bool direct = false;
+    {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, fb) == hipSuccess) direct = at.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();
+    }
+    const size_t fb_bytes = direct ? 0 : npx * 4, id_bytes = hit_ids ? npx * g * g * sizeof(int32_t) : 0, need = fb_bytes + id_bytes + 64;
     if (c->h_stage_bytes < need) {
         if (c->h_stage) (void)hipHostFree(c->h_stage);
         c->h_stage = nullptr; c->h_stage_bytes = 0;
@@ -387,11 +404,16 @@ int mrt_render(mrt_ctx* c, const float cam[16], uint32_t flags, uint32_t* fb, in
     }
     unsigned char* stage = static_cast<unsigned char*>(c->h_stage);
     unsigned long long* wd_stage = reinterpret_cast<unsigned long long*>(stage + fb_bytes + id_bytes);
-    MRT_HIP(c, hipMemcpyAsync(stage, c->d_fb.p, fb_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (direct)
+        MRT_HIP(c, hipMemcpy2DAsync(fb, (size_t)pitch_px * 4, c->d_fb.p, (size_t)c->width * 4, (size_t)c->width * 4, c->height,
+                                    hipMemcpyDeviceToHost, c->stream));
+    else
+        MRT_HIP(c, hipMemcpyAsync(stage, c->d_fb.p, fb_bytes, hipMemcpyDeviceToHost, c->stream));
     if (hit_ids) MRT_HIP(c, hipMemcpyAsync(stage + fb_bytes, c->d_ids.p, id_bytes, hipMemcpyDeviceToHost, c->stream));
     MRT_HIP(c, hipMemcpyAsync(wd_stage, c->d_counters.p + 5, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     MRT_HIP(c, hipStreamSynchronize(c->stream));
-    if (pitch_px == c->width) memcpy(fb, stage, fb_bytes);
+    if (direct) {}
+    else if (pitch_px == c->width) memcpy(fb, stage, fb_bytes);
     else for (int y = 0; y < c->height; ++y) memcpy(fb + (size_t)y * pitch_px, stage + (size_t)y * c->width * 4, (size_t)c->width * 4);
     if (hit_ids) memcpy(hit_ids, stage + fb_bytes, id_bytes);
     const unsigned long long wd = *wd_stage;

@@ -13,11 +13,14 @@
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <strings.h>
 
+#include <algorithm>
 #include <map>
 #include <memory>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -32,13 +35,24 @@ struct vec3 { float x, y, z; };
 
 struct Surface {                       // surface.h:57-100 (pixel storage only)
     int width, height, pitch;
-    std::vector<uint32_t> buffer;
-    Surface(int w, int h) : width(w), height(h), pitch(w), buffer((size_t)w * h, 0u) {}
-    uint32_t* GetBuffer() { return buffer.data(); }
+    uint32_t* buffer;                  // page-locked when a GPU is present (the frame is then written straight into it)
+    bool pinned;
+    Surface(int w, int h) : width(w), height(h), pitch(w) {
+        const size_t bytes = (size_t)w * h * sizeof(uint32_t);
+        buffer = static_cast<uint32_t*>(mrt_host_alloc(bytes));
+        pinned = buffer != nullptr;
+        if (!pinned) buffer = static_cast<uint32_t*>(aligned_alloc(64, (bytes + 63) / 64 * 64));   // surface.cpp:114-120
+        if (!buffer) throw std::bad_alloc();
+        Clear(0);
+    }
+    ~Surface() { if (pinned) mrt_host_free(buffer); else free(buffer); }
+    Surface(const Surface&) = delete;
+    Surface& operator=(const Surface&) = delete;
+    uint32_t* GetBuffer() { return buffer; }
     int GetWidth() const { return width; }
     int GetHeight() const { return height; }
     int GetPitch() const { return pitch; }
-    void Clear(uint32_t c) { std::fill(buffer.begin(), buffer.end(), c); }      // surface.cpp Clear
+    void Clear(uint32_t c) { std::fill(buffer, buffer + (size_t)pitch * height, c); }      // surface.cpp Clear
     bool SavePPM(const std::string& path) const {
         FILE* f = fopen(path.c_str(), "wb");
         if (!f) return false;

@@ -320,6 +320,26 @@ def test_million_triangle_scene_4k_rows_match_oracle():
     rt.close()
 
 
+def test_page_locked_caller_framebuffer(maze_scene):
+    """mrt_render into memory from mrt_host_alloc (written by the GPU directly, also with a pitch wider
+    than the frame) gives the same frame as into an ordinary buffer (staged)."""
+    from raytracing_amd.binding import HostFrame
+    W, H = 256, 128
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(maze_scene)
+    cam = pose_cam(POSES[1])
+    ref, _ = rt.render(cam, mode=MODE_RECURSIVE)
+    hf = HostFrame(H, W)
+    rt.render(cam, mode=MODE_RECURSIVE, fb=hf.array, want_ids=False)
+    assert np.array_equal(hf.array, ref)
+    wide = HostFrame(H, W + 64)
+    wide.array[:] = 0xDEADBEEF
+    rt.render(cam, mode=MODE_RECURSIVE, fb=wide.array[:, :W], want_ids=False)
+    assert np.array_equal(wide.array[:, :W], ref) and (wide.array[:, W:] == 0xDEADBEEF).all()
+    hf.close(); wide.close()
+    rt.close()
+
+
 def test_error_paths(maze_scene):
     rt = Raytracer(64, 64, device=0)
     with pytest.raises(MrtError, match="scene_upload"):
