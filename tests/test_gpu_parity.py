@@ -340,6 +340,22 @@ def test_page_locked_caller_framebuffer(maze_scene):
     rt.close()
 
 
+def test_root_gate_quirk_on_gpu(maze_scene, known):
+    """The recorded effect of the reference's root-gate quirk, reproduced by the GPU alone: number of
+    800x600 primary rays whose hit differs between the packet path (no gate) and the recursive shader."""
+    rt = Raytracer(800, 600, device=0)
+    rt.build_bvh(maze_scene)
+    for k in known["root_gate_800x600"]:
+        cam = Camera()
+        if k["pose"] is not None:
+            cam.set_position(k["pose"]["pos"])
+            cam.look_at(k["pose"]["target"])
+        _, a = rt.render(cam, mode=MODE_PACKET)
+        _, b = rt.render(cam, mode=MODE_RECURSIVE)
+        assert int((a != b).sum()) == k["rays_changed_by_gate"] == int(((a >= 0) & (b < 0)).sum())
+    rt.close()
+
+
 def test_error_paths(maze_scene):
     rt = Raytracer(64, 64, device=0)
     with pytest.raises(MrtError, match="scene_upload"):

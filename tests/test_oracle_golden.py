@@ -163,3 +163,27 @@ def test_packet_equals_scalar_equals_bruteforce(maze_oracle):
         tri2, t2, uv2 = maze_oracle.trace_ray_brute(O, D, 1e8)
         assert tri == tri2 == int(r["ids"][y, x])
         assert bits([t])[0] == bits([t2])[0] == bits(r["tuv"][y, x, 0:1])[0]
+
+
+def _gate_cases(known):
+    for k in known["root_gate_800x600"]:
+        cam = oracle_lib.IDENTITY if k["pose"] is None else oracle_lib.lookat(k["pose"]["pos"], k["pose"]["target"])
+        yield cam, k["rays_changed_by_gate"]
+
+
+def test_root_gate_quirk_changes_the_recorded_number_of_rays(maze_oracle, known):
+    """BVH::Traverse hands CheckBox the direction instead of its reciprocal (raytracer.cpp:947).  The
+    survey measured how many of the 480,000 primary rays of an 800x600 frame get a different answer
+    because of it: 1,229 at the default pose, 54,959 from (3,4,10).  The packet path has no gate, the
+    recursive shader's primary ray goes through it."""
+    for cam, n in _gate_cases(known):
+        a = maze_oracle.render(cam, 800, 600, mode=0)["ids"]
+        b = maze_oracle.render(cam, 800, 600, mode=1)["ids"]
+        assert int((a != b).sum()) == n
+        assert int(((a >= 0) & (b < 0)).sum()) == n          # the gate only ever loses hits
+
+
+def test_recursive_vs_packet_fraction_at_full_hd(maze_oracle, known):
+    a = maze_oracle.render(oracle_lib.IDENTITY, 1920, 1080, mode=0, want_ids=False)["fb"]
+    b = maze_oracle.render(oracle_lib.IDENTITY, 1920, 1080, mode=1, want_ids=False)["fb"]
+    assert abs(float((a != b).mean()) - known["recursive_vs_packet_fraction"]["1920x1080_P0"]) < 0.0005
