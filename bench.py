@@ -327,14 +327,18 @@ def main():
         out["c3_1m_tris_4k"] = {"workload": "synthetic 1,000,000-triangle soup (LCG seed 12345), 3840x2160, packet path + shadow rays",
                                 "value": round(r3["mrays_per_s"], 3), "unit": "Mrays/s", "ms_per_step": round(r3["ms_per_step"], 4),
                                 "kernel_ms": round(r3["kernel_ms"], 4), "rays_per_frame": r3["rays_per_step"]}
-        fbh = np.zeros((2160, 3840), np.uint32)
-        c3.rt.raster(cam, fb=fbh, want_z=False, want_ids=False)
+        from raytracing_amd.binding import HostFrame
+        hf = HostFrame(2160, 3840)
+        hf.array[:] = 0
+        c3.rt.raster(cam, fb=hf.array, want_z=False, want_ids=False)
         t0 = time.perf_counter()
-        for _ in range(5):
-            c3.rt.raster(cam, fb=fbh, want_z=False, want_ids=False)
-        out["c5_raster_1m_4k"] = {"workload": "rasterizer path, same soup, 3840x2160, host framebuffer copy included",
-                                  "ms_per_frame": round((time.perf_counter() - t0) / 5 * 1e3, 3),
-                                  "covered_fraction": round(float((fbh != 0).mean()), 4)}
+        for _ in range(10):
+            c3.rt.raster(cam, fb=hf.array, want_z=False, want_ids=False)
+        out["c5_raster_1m_4k"] = {"workload": "rasterizer path, same soup, 3840x2160, frame written into page-locked host memory "
+                                              "(the rasterizer has no device-resident entry point)",
+                                  "ms_per_frame": round((time.perf_counter() - t0) / 10 * 1e3, 3),
+                                  "covered_fraction": round(float((hf.array != 0).mean()), 4)}
+        hf.close()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

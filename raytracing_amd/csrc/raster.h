@@ -45,13 +45,15 @@ struct RasterState {
     int32_t* d_tri = nullptr;        // per triangle, 3 vertex indices into d_pos/d_uv (already offset)
     int32_t* d_tri_tex = nullptr;    // per triangle: texture index, or -1 when its mesh is culled / untextured
     RasterTri* d_setup = nullptr;
-    uint2* d_chunks = nullptr;       // work items of the coverage kernel: {triangle, first 8x8 block}
-    size_t chunk_capacity = 0;
-    uint32_t* d_chunk_base = nullptr; // per triangle: first chunk slot
-    uint32_t* d_total = nullptr;     // [0] chunks needed this frame
+    uint32_t* d_chunk_base = nullptr; // n_tris words: list of the triangles that overlap many tiles
+    uint32_t* d_total = nullptr;     // [0] (tile, triangle) pairs this frame, [1] length of the big-triangle list
+    uint32_t* d_tile_count = nullptr; // per 32x32 tile: triangle count, then fill cursor
+    uint32_t* d_tile_start = nullptr; // per tile (+1): start of its list in d_pairs
+    uint32_t n_tile_slots = 0;
+    uint32_t* d_pairs = nullptr;     // triangle indices, grouped by tile
+    size_t pair_capacity = 0;
     uint32_t n_verts = 0, n_tris = 0;
     std::vector<int32_t> h_tri_mesh; // per triangle: mesh index
-    unsigned long long* d_depth = nullptr;   // W*H packed {orderable 1/z, triangle index}
     uint32_t* d_fb = nullptr;
     float* d_z = nullptr;
     int32_t* d_ids = nullptr;

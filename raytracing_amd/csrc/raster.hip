@@ -1,20 +1,22 @@
-// Rasterizer path: Rasterizer::Render / RenderMesh (rasterizer.cpp:53-184) as three kernels.
+// Rasterizer path: Rasterizer::Render / RenderMesh (rasterizer.cpp:53-184) as a tiled pipeline.
 //
-//   raster_setup    one thread per triangle: vertex transform, back-face cull, Sutherland-Hodgman
-//                   clip against the near and left planes, projection, palette level, and the
-//                   screen-space plane equations of 1/z, u/z and v/z (rasterizer.cpp:100-141).
-//   raster_emit     cuts every triangle's pixel bounding box into chunks of kChunkBlocks 8x8 blocks
-//                   and appends one work item per chunk, so a screen-filling triangle is spread
-//                   over hundreds of waves while a small one costs a single wave.
-//   raster_cover    one wave per chunk, one lane per pixel of an 8x8 block;
-//                   a pixel is covered exactly when the reference's scan conversion would plot it
-//                   (rows y0 < y <= y1 of the spanning edges, columns xl < x <= xr of the row's
-//                   extent, rasterizer.cpp:143-182), and the depth test is a 64-bit atomicMin on
-//                   {orderable 1/z, triangle index}: the reference draws triangles in order and
-//                   skips a pixel when the new 1/z is >= the stored one, i.e. the smallest 1/z
-//                   wins and, among equals, the first triangle drawn.
-//   raster_resolve  one thread per pixel: texel fetch and palette lookup of the winner
-//                   (rasterizer.cpp:178-180), optional 1/z and triangle-id planes.
+//   raster_setup      one thread per triangle: vertex transform, back-face cull, Sutherland-Hodgman
+//                     clip against the near and left planes, projection, palette level, per-edge
+//                     constants and the screen-space plane equations of 1/z, u/z and v/z
+//                     (rasterizer.cpp:100-141).
+//   raster_bin_*      bin the triangles' pixel bounding boxes to 32x32-pixel screen tiles: count per
+//                     tile, exclusive scan, fill (a triangle overlapping more than 16 tiles is
+//                     binned by a whole wave, lanes striding over its tiles).
+//   raster_tile       one workgroup per tile, depth cells of the tile in LDS.  Each wave takes every
+//                     fourth triangle of the tile's list; one lane per pixel of an 8x8 block.  A
+//                     pixel is covered exactly when the reference's scan conversion would plot it
+//                     (rows y0 < y <= y1 of the spanning edges, columns xl < x <= xr of the row's
+//                     extent, rasterizer.cpp:143-182), and the depth test is a 64-bit LDS atomicMin
+//                     on {orderable 1/z, triangle index}: the reference draws triangles in order and
+//                     skips a pixel when the new 1/z is >= the stored one, i.e. the smallest 1/z
+//                     wins and, among equals, the first triangle drawn.  The workgroup then resolves
+//                     its own pixels: texel fetch and palette lookup of the winner
+//                     (rasterizer.cpp:178-180), optional 1/z and triangle-id planes.
 //
 // The reference interpolates along edges and spans by repeated addition; here the same affine
 // functions are evaluated directly, so results differ only where a pixel centre lies within
@@ -154,7 +156,11 @@ __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* 
 __device__ __forceinline__ bool covers(const RasterTri& T, int x, int y, int W) {
     float xl = (float)(W - 1), xr = 0.0f;             // the outline tables' idle values, :28, :164
     bool any = false;
-    for (int j = 0; j < T.n; ++j) {
+    // unrolled over the five possible edges: with constant indices the triangle record, which is the
+    // same for the whole wave, stays in scalar registers instead of being re-read per lane and edge
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        if (j >= T.n) break;
         if (y < T.iy0[j] || y > T.iy1[j]) continue;
         const float xe = T.ex[j] + T.dx[j] * ((float)y - T.ey[j]);
         if (xe < xl) xl = xe;
@@ -166,85 +172,139 @@ __device__ __forceinline__ bool covers(const RasterTri& T, int x, int y, int W) 
     return x >= ix0 && x <= ix1;
 }
 
-constexpr int kChunkBlocks = 16;     // 8x8 blocks per coverage work item
-
-__device__ __forceinline__ uint32_t tri_blocks(const RasterTri& T) {
-    if (T.n == 0) return 0;
-    const uint32_t bw = (uint32_t)((T.x1 >> 3) - (T.x0 >> 3) + 1), bh = (uint32_t)((T.y1 >> 3) - (T.y0 >> 3) + 1);
-    return bw * bh;
-}
-
-// pass 1: reserve chunk slots per triangle
-__global__ __launch_bounds__(256) void raster_count(const RasterTri* setup, uint32_t n_tris, uint32_t* chunk_base, uint32_t* total) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tris) return;
-    const uint32_t nb = tri_blocks(setup[t]);
-    const uint32_t nc = (nb + kChunkBlocks - 1) / kChunkBlocks;
-    chunk_base[t] = nc ? atomicAdd(total, nc) : 0u;
-}
-// pass 2: write the work items
-__global__ __launch_bounds__(256) void raster_emit(const RasterTri* setup, uint32_t n_tris, const uint32_t* chunk_base, uint2* chunks) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tris) return;
-    const uint32_t nb = tri_blocks(setup[t]);
-    const uint32_t nc = (nb + kChunkBlocks - 1) / kChunkBlocks;
-    for (uint32_t c = 0; c < nc; ++c) chunks[chunk_base[t] + c] = make_uint2(t, c * kChunkBlocks);
-}
-
-__global__ __launch_bounds__(64) void raster_cover(const RasterTri* setup, const uint2* chunks, uint32_t n_chunks,
-                                                   unsigned long long* depth, int W, int H) {
-    if (blockIdx.x >= n_chunks) return;
-    const uint2 item = chunks[blockIdx.x];
-    const uint32_t t = item.x;
-    const RasterTri T = setup[t];
-    const int lane = threadIdx.x;
-    const int bx0 = T.x0 >> 3, by0 = T.y0 >> 3;
-    const uint32_t bw = (uint32_t)((T.x1 >> 3) - bx0 + 1);
-    const uint32_t nb = tri_blocks(T);
-    const uint32_t end = min(item.y + (uint32_t)kChunkBlocks, nb);
-    for (uint32_t b = item.y; b < end; ++b) {
-        const int x = ((bx0 + (int)(b % bw)) << 3) + (lane & 7), y = ((by0 + (int)(b / bw)) << 3) + (lane >> 3);
-        if (x < T.x0 || x > T.x1 || y < T.y0 || y > T.y1) continue;
-        if (!covers(T, x, y, W)) continue;
-        const float z0 = T.zA * (float)x + T.zB * (float)y + T.zC;
-        if (!(z0 < 0.0f)) continue;                     // the z-buffer is cleared to 0 and the test is "z0 >= zbuf: skip" (:55, :177)
-        const unsigned long long key = ((unsigned long long)orderable(z0) << 32) | t;
-        atomicMin(&depth[(size_t)y * W + x], key);
-    }
-}
-
-__global__ __launch_bounds__(256) void raster_resolve(const RasterTri* setup, const unsigned long long* depth, RasterTextures tx,
-                                                       uint32_t* fb, float* zbuf, int32_t* ids, int W, int H) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= W || y >= H) return;
-    const size_t p = (size_t)y * W + x;
-    const unsigned long long key = depth[p];
+// texel fetch and palette lookup of a pixel's depth winner (rasterizer.cpp:178-180)
+__device__ __forceinline__ void resolve_pixel(const RasterTri* setup, unsigned long long key, const RasterTextures& tx, int x, int y,
+                                              size_t p, uint32_t* fb, size_t pf, bool keep_uncovered, float* zbuf, int32_t* ids) {
+    // p: index into the W-pitched z and id planes; pf: index into fb (the caller's pitch when fb is the caller's
+    // own page-locked frame, in which case pixels nothing covers are left as they are: keep_uncovered)
     const uint32_t t = (uint32_t)key;
     if (t == 0xffffffffu) {
         if (zbuf) zbuf[p] = 0.0f;
         if (ids) ids[p] = -1;
-        fb[p] = kUncovered;              // palette entries are 0x00RRGGBB, so this value marks "nothing drawn here"
+        if (!keep_uncovered) fb[pf] = kUncovered;   // palette entries are 0x00RRGGBB, so this value marks "nothing drawn here"
         return;
     }
-    const RasterTri T = setup[t];
+    const RasterTri& T = setup[t];
     const float z0 = from_orderable((unsigned int)(key >> 32));
     const float u0 = T.uA * (float)x + T.uB * (float)y + T.uC;
     const float v0 = T.vA * (float)x + T.vB * (float)y + T.vC;
-    const int4 td = tx.tex[T.texture];
+    const int texture = T.texture;
+    const int4 td = tx.tex[texture];
     const float tw = (float)td.y, th = (float)td.z;
     const int umask = td.y - 1, vmask = td.z - 1;
-    const float z = 1.0f / z0;                                                  // rasterizer.cpp:178-180
+    const float z = 1.0f / z0;
     const int u = (int)(u0 * z * tw) & umask, v = (int)(v0 * z * th) & vmask;
     const uint32_t texel = tx.texels[(size_t)td.x + (size_t)(u + v * (umask + 1))];
-    fb[p] = tx.pal[(size_t)T.texture * (32 * 256) + (size_t)T.level * 256 + texel];
+    fb[pf] = tx.pal[(size_t)texture * (32 * 256) + (size_t)T.level * 256 + texel];
     if (zbuf) zbuf[p] = z0;
     if (ids) ids[p] = (int32_t)t;
 }
 
-__global__ void raster_clear(unsigned long long* depth, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // 1/z = 0 (the cleared z-buffer) with no triangle: every negative 1/z is smaller
-    if (i < n) depth[i] = ((unsigned long long)orderable(0.0f) << 32) | 0xffffffffull;
+// ---------------------------------------------------------------------------------------
+// Tiled path: triangles are binned to 32x32-pixel screen tiles, and one workgroup per tile keeps
+// the tile's depth cells in LDS, so the depth test is an LDS atomic instead of a device-scope
+// atomic in memory, and resolves its own pixels.  The result is the same minimum over
+// {1/z, triangle index} per pixel, whatever the order in which a tile meets its triangles.
+// ---------------------------------------------------------------------------------------
+constexpr int kTile = 32, kTileShift = 5;
+constexpr int kSmallTiles = 16;          // a triangle overlapping more tiles than this is binned by a whole wave
+constexpr int kBigWaves = 1024;
+
+struct TileRange { int tx0, ty0, tw, th; };
+__device__ __forceinline__ TileRange tile_range(const RasterTri& T) {
+    TileRange r;
+    r.tx0 = T.x0 >> kTileShift; r.ty0 = T.y0 >> kTileShift;
+    r.tw = (T.x1 >> kTileShift) - r.tx0 + 1; r.th = (T.y1 >> kTileShift) - r.ty0 + 1;
+    return r;
+}
+
+// FILL = false: count the triangles of every tile, and list the big triangles.  FILL = true: write the
+// tiles' triangle lists (tile_start from the scan; cursor = running fill position per tile).
+template <bool FILL>
+__global__ __launch_bounds__(256) void raster_bin_small(const RasterTri* setup, uint32_t n_tris, int tiles_x, uint32_t* tile_count,
+                                                         const uint32_t* tile_start, uint32_t* pairs, uint32_t* big, uint32_t* big_count) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tris) return;
+    const RasterTri& T = setup[t];
+    if (T.n == 0) return;
+    const TileRange r = tile_range(T);
+    if (r.tw * r.th > kSmallTiles) {
+        if (!FILL) big[atomicAdd(big_count, 1u)] = t;
+        return;
+    }
+    for (int j = 0; j < r.th; ++j)
+        for (int i = 0; i < r.tw; ++i) {
+            const uint32_t tile = (uint32_t)((r.ty0 + j) * tiles_x + r.tx0 + i);
+            const uint32_t slot = atomicAdd(&tile_count[tile], 1u);
+            if (FILL) pairs[tile_start[tile] + slot] = t;
+        }
+}
+template <bool FILL>
+__global__ __launch_bounds__(256) void raster_bin_big(const RasterTri* setup, int tiles_x, uint32_t* tile_count, const uint32_t* tile_start,
+                                                       uint32_t* pairs, const uint32_t* big, const uint32_t* big_count) {
+    const uint32_t n = *big_count;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += kBigWaves) {
+        const uint32_t t = big[i];
+        const TileRange r = tile_range(setup[t]);
+        for (int k = lane; k < r.tw * r.th; k += 64) {
+            const uint32_t tile = (uint32_t)((r.ty0 + k / r.tw) * tiles_x + r.tx0 + k % r.tw);
+            const uint32_t slot = atomicAdd(&tile_count[tile], 1u);
+            if (FILL) pairs[tile_start[tile] + slot] = t;
+        }
+    }
+}
+// exclusive scan of the tile counts by one workgroup; total[0] receives the number of (tile, triangle) pairs
+__global__ __launch_bounds__(1024) void raster_tile_scan(const uint32_t* tile_count, uint32_t* tile_start, uint32_t n_tiles, uint32_t* total) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (n_tiles + 1023) / 1024, b = threadIdx.x * per, e = min(b + per, n_tiles);
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < e; ++i) sum += tile_count[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t i = b; i < e; ++i) { tile_start[i] = run; run += tile_count[i]; }
+    if (threadIdx.x == 1023) { tile_start[n_tiles] = part[1023]; total[0] = part[1023]; }
+}
+
+__global__ __launch_bounds__(256) void raster_tile(const RasterTri* setup, const uint32_t* tile_start, const uint32_t* pairs, int tiles_x,
+                                                   RasterTextures tx, uint32_t* fb, int fb_pitch, int keep_uncovered, float* zbuf, int32_t* ids,
+                                                   int W, int H) {
+    __shared__ unsigned long long cell[kTile * kTile];
+    const unsigned long long empty = ((unsigned long long)orderable(0.0f) << 32) | 0xffffffffull;   // the cleared z-buffer, no triangle
+    for (int p = threadIdx.x; p < kTile * kTile; p += 256) cell[p] = empty;
+    __syncthreads();
+    const int tile = blockIdx.x, px0 = (tile % tiles_x) << kTileShift, py0 = (tile / tiles_x) << kTileShift;
+    const int lane = threadIdx.x & 63;
+    const uint32_t begin = tile_start[tile], end = tile_start[tile + 1];
+    for (uint32_t i = begin + (threadIdx.x >> 6); i < end; i += 4) {
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)pairs[i]);
+        const RasterTri& T = setup[t];
+        const int bx0 = max(T.x0, px0) >> 3, bx1 = min(T.x1, px0 + kTile - 1) >> 3;
+        const int by0 = max(T.y0, py0) >> 3, by1 = min(T.y1, py0 + kTile - 1) >> 3;
+        for (int by = by0; by <= by1; ++by)
+            for (int bx = bx0; bx <= bx1; ++bx) {
+                const int x = (bx << 3) + (lane & 7), y = (by << 3) + (lane >> 3);
+                if (x < T.x0 || x > T.x1 || y < T.y0 || y > T.y1) continue;
+                if (!covers(T, x, y, W)) continue;
+                const float z0 = T.zA * (float)x + T.zB * (float)y + T.zC;
+                if (!(z0 < 0.0f)) continue;             // the z-buffer is cleared to 0 and the test is "z0 >= zbuf: skip" (:55, :177)
+                const unsigned long long key = ((unsigned long long)orderable(z0) << 32) | t;
+                atomicMin(&cell[(y - py0) * kTile + (x - px0)], key);
+            }
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < kTile * kTile; p += 256) {
+        const int x = px0 + (p & (kTile - 1)), y = py0 + (p >> kTileShift);
+        if (x < W && y < H)
+            resolve_pixel(setup, cell[p], tx, x, y, (size_t)y * W + x, fb, (size_t)y * fb_pitch + x, keep_uncovered != 0, zbuf, ids);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -258,8 +318,8 @@ __global__ void raster_clear(unsigned long long* depth, size_t n) {
 
 void raster_release(RasterState& R) {
     for (void* p : {(void*)R.d_pos, (void*)R.d_uv, (void*)R.d_N, (void*)R.d_tri, (void*)R.d_tri_tex, (void*)R.d_setup,
-                    (void*)R.d_chunks, (void*)R.d_chunk_base, (void*)R.d_total,
-                    (void*)R.d_depth, (void*)R.d_fb, (void*)R.d_z, (void*)R.d_ids})
+                    (void*)R.d_pairs, (void*)R.d_chunk_base, (void*)R.d_total, (void*)R.d_tile_count, (void*)R.d_tile_start,
+                    (void*)R.d_fb, (void*)R.d_z, (void*)R.d_ids})
         if (p) (void)hipFree(p);
     if (R.h_stage) (void)hipHostFree(R.h_stage);
     R = RasterState();
@@ -326,9 +386,8 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
                   float* zbuf, int32_t* tri_ids, hipStream_t stream, std::string& err) {
     const size_t npx = (size_t)W * H;
     if (R.frame_px != npx) {
-        for (void* p : {(void*)R.d_depth, (void*)R.d_fb, (void*)R.d_z, (void*)R.d_ids}) if (p) (void)hipFree(p);
-        R.d_depth = nullptr; R.d_fb = nullptr; R.d_z = nullptr; R.d_ids = nullptr;
-        RASTER_HIP(hipMalloc((void**)&R.d_depth, npx * 8));
+        for (void* p : {(void*)R.d_fb, (void*)R.d_z, (void*)R.d_ids}) if (p) (void)hipFree(p);
+        R.d_fb = nullptr; R.d_z = nullptr; R.d_ids = nullptr;
         RASTER_HIP(hipMalloc((void**)&R.d_fb, npx * 4));
         RASTER_HIP(hipMalloc((void**)&R.d_z, npx * 4));
         RASTER_HIP(hipMalloc((void**)&R.d_ids, npx * 4));
@@ -366,33 +425,61 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
     memcpy(F.M, &M, 64);
     for (int p = 0; p < 2; ++p) { F.frustum[p][0] = frustum[p].x; F.frustum[p][1] = frustum[p].y; F.frustum[p][2] = frustum[p].z; F.frustum[p][3] = frustum[p].w; }
     F.W = W; F.H = H;
-    hipLaunchKernelGGL(raster_clear, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, R.d_depth, npx);
+    const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile;
+    const uint32_t n_tiles = (uint32_t)(tiles_x * tiles_y);
+    if (R.n_tile_slots < n_tiles + 1) {
+        for (void* p : {(void*)R.d_tile_count, (void*)R.d_tile_start}) if (p) (void)hipFree(p);
+        R.d_tile_count = nullptr; R.d_tile_start = nullptr; R.n_tile_slots = 0;
+        RASTER_HIP(hipMalloc((void**)&R.d_tile_count, (size_t)(n_tiles + 1) * 4));
+        RASTER_HIP(hipMalloc((void**)&R.d_tile_start, (size_t)(n_tiles + 1) * 4));
+        R.n_tile_slots = n_tiles + 1;
+    }
+    RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_tiles + 1) * 4, stream));
+    RASTER_HIP(hipMemsetAsync(R.d_tile_start, 0, (size_t)(n_tiles + 1) * 4, stream));
     if (R.n_tris > 0) {
+        const dim3 per_tri((R.n_tris + 255) / 256), b256(256);
         RASTER_HIP(hipMemcpyAsync(R.d_tri_tex, tri_tex.data(), (size_t)R.n_tris * 4, hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(raster_setup, dim3((R.n_tris + 255) / 256), dim3(256), 0, stream, F, R.d_pos, R.d_uv, R.d_N, R.d_tri,
-                           R.d_tri_tex, R.d_setup, R.n_tris);
-        RASTER_HIP(hipMemsetAsync(R.d_total, 0, 4, stream));
-        hipLaunchKernelGGL(raster_count, dim3((R.n_tris + 255) / 256), dim3(256), 0, stream, R.d_setup, R.n_tris, R.d_chunk_base, R.d_total);
-        uint32_t n_chunks = 0;
-        RASTER_HIP(hipMemcpyAsync(&n_chunks, R.d_total, 4, hipMemcpyDeviceToHost, stream));
+        hipLaunchKernelGGL(raster_setup, per_tri, b256, 0, stream, F, R.d_pos, R.d_uv, R.d_N, R.d_tri, R.d_tri_tex, R.d_setup, R.n_tris);
+        RASTER_HIP(hipMemsetAsync(R.d_total, 0, 16, stream));          // [0] pairs, [1] big triangles
+        hipLaunchKernelGGL((raster_bin_small<false>), per_tri, b256, 0, stream, R.d_setup, R.n_tris, tiles_x, R.d_tile_count, R.d_tile_start,
+                           (uint32_t*)nullptr, R.d_chunk_base, R.d_total + 1);
+        hipLaunchKernelGGL((raster_bin_big<false>), dim3(kBigWaves / 4), b256, 0, stream, R.d_setup, tiles_x, R.d_tile_count, R.d_tile_start,
+                           (uint32_t*)nullptr, R.d_chunk_base, R.d_total + 1);
+        hipLaunchKernelGGL(raster_tile_scan, dim3(1), dim3(1024), 0, stream, R.d_tile_count, R.d_tile_start, n_tiles, R.d_total);
+        uint32_t n_pairs = 0;
+        RASTER_HIP(hipMemcpyAsync(&n_pairs, R.d_total, 4, hipMemcpyDeviceToHost, stream));
         RASTER_HIP(hipStreamSynchronize(stream));
-        if (n_chunks > R.chunk_capacity) {
-            if (R.d_chunks) (void)hipFree(R.d_chunks);
-            R.d_chunks = nullptr; R.chunk_capacity = 0;
-            const size_t cap = (size_t)n_chunks + n_chunks / 4 + 1024;
-            RASTER_HIP(hipMalloc((void**)&R.d_chunks, cap * sizeof(uint2)));
-            R.chunk_capacity = cap;
+        if (n_pairs > R.pair_capacity) {
+            if (R.d_pairs) (void)hipFree(R.d_pairs);
+            R.d_pairs = nullptr; R.pair_capacity = 0;
+            const size_t cap = (size_t)n_pairs + n_pairs / 4 + 1024;
+            RASTER_HIP(hipMalloc((void**)&R.d_pairs, cap * 4));
+            R.pair_capacity = cap;
         }
-        if (n_chunks > 0) {
-            hipLaunchKernelGGL(raster_emit, dim3((R.n_tris + 255) / 256), dim3(256), 0, stream, R.d_setup, R.n_tris, R.d_chunk_base, R.d_chunks);
-            hipLaunchKernelGGL(raster_cover, dim3(n_chunks), dim3(64), 0, stream, R.d_setup, R.d_chunks, n_chunks, R.d_depth, W, H);
+        if (n_pairs > 0) {
+            RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_tiles + 1) * 4, stream));      // now the fill cursors
+            hipLaunchKernelGGL((raster_bin_small<true>), per_tri, b256, 0, stream, R.d_setup, R.n_tris, tiles_x, R.d_tile_count, R.d_tile_start,
+                               R.d_pairs, R.d_chunk_base, R.d_total + 1);
+            hipLaunchKernelGGL((raster_bin_big<true>), dim3(kBigWaves / 4), b256, 0, stream, R.d_setup, tiles_x, R.d_tile_count, R.d_tile_start,
+                               R.d_pairs, R.d_chunk_base, R.d_total + 1);
         }
     }
-    hipLaunchKernelGGL(raster_resolve, dim3((unsigned)((W + 255) / 256), (unsigned)H), dim3(256), 0, stream, R.d_setup, R.d_depth, tx,
-                       R.d_fb, zbuf ? R.d_z : nullptr, tri_ids ? R.d_ids : nullptr, W, H);
+    // A frame in page-locked memory (mrt_host_alloc) is written by the kernel itself, covered pixels only; any
+    // other frame comes back through page-locked staging and its covered pixels are merged in on the host
+    // (the reference only plots covered pixels, so the rest must stay as the caller had it).
+    uint32_t* fb_direct = nullptr;
+    {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, fb) == hipSuccess && at.type == hipMemoryTypeHost) {
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, fb, 0) == hipSuccess) fb_direct = static_cast<uint32_t*>(dp);
+        }
+        (void)hipGetLastError();
+    }
+    hipLaunchKernelGGL(raster_tile, dim3(n_tiles), dim3(256), 0, stream, R.d_setup, R.d_tile_start, R.d_pairs, tiles_x, tx,
+                       fb_direct ? fb_direct : R.d_fb, fb_direct ? pitch_px : W, fb_direct ? 1 : 0,
+                       zbuf ? R.d_z : nullptr, tri_ids ? R.d_ids : nullptr, W, H);
     RASTER_HIP(hipGetLastError());
-    // Pixels no triangle covers are left as the caller had them (the reference only plots covered
-    // pixels): the frame comes back through page-locked staging and covered pixels are merged in.
     const size_t need = npx * 4 + (tri_ids ? npx * 4 : 0) + (zbuf ? npx * 4 : 0);
     if (R.h_stage_bytes < need) {
         if (R.h_stage) (void)hipHostFree(R.h_stage);
@@ -403,17 +490,18 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
     unsigned char* stage = static_cast<unsigned char*>(R.h_stage);
     uint32_t* h_fb = reinterpret_cast<uint32_t*>(stage);
     unsigned char* next = stage + npx * 4;
-    RASTER_HIP(hipMemcpyAsync(h_fb, R.d_fb, npx * 4, hipMemcpyDeviceToHost, stream));
+    if (!fb_direct) RASTER_HIP(hipMemcpyAsync(h_fb, R.d_fb, npx * 4, hipMemcpyDeviceToHost, stream));
     if (tri_ids) { RASTER_HIP(hipMemcpyAsync(next, R.d_ids, npx * 4, hipMemcpyDeviceToHost, stream)); }
     unsigned char* ids_stage = next;
     if (tri_ids) next += npx * 4;
     if (zbuf) RASTER_HIP(hipMemcpyAsync(next, R.d_z, npx * 4, hipMemcpyDeviceToHost, stream));
     RASTER_HIP(hipStreamSynchronize(stream));      // tri_tex goes out of scope after this
-    for (int y = 0; y < H; ++y) {
-        const uint32_t* src = h_fb + (size_t)y * W;
-        uint32_t* dst = fb + (size_t)y * pitch_px;
-        for (int x = 0; x < W; ++x) dst[x] = src[x] == kUncovered ? dst[x] : src[x];
-    }
+    if (!fb_direct)
+        for (int y = 0; y < H; ++y) {
+            const uint32_t* src = h_fb + (size_t)y * W;
+            uint32_t* dst = fb + (size_t)y * pitch_px;
+            for (int x = 0; x < W; ++x) dst[x] = src[x] == kUncovered ? dst[x] : src[x];
+        }
     if (tri_ids) memcpy(tri_ids, ids_stage, npx * 4);
     if (zbuf) memcpy(zbuf, next, npx * 4);
     return MRT_OK;

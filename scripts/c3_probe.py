@@ -49,6 +49,15 @@ def main():
     for _ in range(3):
         rt.raster(cam, fb=fbh, want_z=False, want_ids=False)
     print("raster    %dx%d  %.2f ms/frame (host copy included), %.1f %% of pixels covered" % (W, H, (time.time() - t0) / 3 * 1e3, 100.0 * (fbh != 0).mean()), flush=True)
+    from raytracing_amd.binding import HostFrame
+    hf = HostFrame(H, W)
+    hf.array[:] = 0
+    rt.raster(cam, fb=hf.array, want_z=False, want_ids=False)
+    t0 = time.time()
+    for _ in range(5):
+        rt.raster(cam, fb=hf.array, want_z=False, want_ids=False)
+    print("raster    %dx%d  %.2f ms/frame into a page-locked caller frame, identical: %s" % (W, H, (time.time() - t0) / 5 * 1e3, np.array_equal(hf.array, fbh)), flush=True)
+    hf.close()
     if check:
         o = oracle_lib.Oracle()
         o.add_scene(scene)

@@ -51,3 +51,22 @@ def test_raster_soup_matches_oracle():
     frac = _check(rt, ora, oracle_lib.IDENTITY, 640, 360)
     assert frac > 0.5
     rt.close()
+
+
+def test_raster_into_page_locked_frame(maze_scene):
+    """A caller frame from mrt_host_alloc is written by the kernel itself (covered pixels only, caller's
+    pitch): same result as the staged path, pixels outside the frame's width untouched."""
+    from raytracing_amd.binding import HostFrame
+    W, H = 320, 200
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(maze_scene)
+    cam = pose_cam(POSES[1])
+    ref = np.full((H, W), 0x00123456, np.uint32)
+    ref, _, ids = rt.raster(cam, fb=ref)
+    assert (ids < 0).any() and (ids >= 0).any()
+    wide = HostFrame(H, W + 32)
+    wide.array[:] = 0x00123456
+    rt.raster(cam, fb=wide.array[:, :W], want_z=False, want_ids=False)
+    assert np.array_equal(wide.array[:, :W], ref) and (wide.array[:, W:] == 0x00123456).all()
+    wide.close()
+    rt.close()
