@@ -286,8 +286,8 @@ def test_8k_16spp_frame_rows_match_oracle(maze_scene, maze_oracle):
 
 
 def test_million_triangle_scene_4k_rows_match_oracle():
-    """The large-scene configuration at its full size: 1,000,000-triangle soup, 3840x2160, scene in
-    global memory.  BVH arrays identical to the oracle's; strips of the packet frame and of the
+    """The large-scene and the rasterizer configurations at their full size: 1,000,000-triangle soup,
+    3840x2160, scene in global memory.  BVH arrays identical to the oracle's; strips of the packet frame and of the
     recursive frame (hit ids and pixels) equal the oracle's."""
     import torch
     W, H = 3840, 2160
@@ -317,6 +317,10 @@ def test_million_triangle_scene_4k_rows_match_oracle():
             torch.cuda.synchronize()
             assert np.array_equal(ids.cpu().numpy(), ref_ids), "mode %d tile row %d" % (mode, R)
             assert colour_mismatch_fraction(strip.cpu().numpy().view(np.uint32), ref_fb) <= 0.001
+    # the rasterizer configuration on the same scene and size: coverage, depth winner, colours, 1/z
+    from test_gpu_raster import _check
+    covered = _check(rt, ora, cam, W, H)
+    assert covered > 0.99
     rt.close()
 
 
