@@ -182,3 +182,17 @@ def test_exact_division_shortcut_matches_ieee_division(tmp_path):
     r = subprocess.run([exe, "20000000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
     assert "mismatches=0" in r.stdout
+
+
+def test_bvh_builder_under_sanitizers(tmp_path):
+    """bvh_builder.cpp compiled for the host with -fsanitize=address,undefined: 40 scenes (random, many
+    equal keys, flat, degenerate triangles, 0..4 triangles), every triangle in exactly one reachable leaf."""
+    import subprocess
+    exe = str(tmp_path / "bvh_sanitize")
+    csrc = os.path.join(ROOT, "raytracing_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                           "-ffp-contract=off", "-I" + csrc, "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                           os.path.join(ROOT, "tests", "native", "bvh_sanitize.cpp"), os.path.join(csrc, "bvh_builder.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-2000:]
+    assert "trial 39" in r.stdout and "runtime error" not in r.stderr
