@@ -5,18 +5,27 @@
 //   mrt_game [--scene assets/maze.obj | scene.mrts] [--size W H] [--frames N]
 //            [--mode packet|recursive|raster] [--pos x y z --lookat x y z]
 //            [--out frame.ppm] [--dump-scene out.mrts] [--device N]
+//            [--script "W*30 RIGHT*10 O*5 SPACE*1" --dt 0.016] [--no-render]
+//
+// --script replays Game::HandleInput (game.cpp:41-75) without a keyboard: each token holds one key for N
+// frames of length dt (W S A D R F move, LEFT RIGHT UP DOWN turn, O P move the light, SPACE switches
+// between ray tracer and rasterizer).  --no-render runs the script only and prints the final state.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sstream>
 #include <string>
+#include <vector>
 
 #include "mrt_host.hpp"
 
 using namespace mrt_host;
 
 int main(int argc, char** argv) {
-    std::string scene_file = "assets/maze.obj", mode = "packet", out, dump;
+    std::string scene_file = "assets/maze.obj", mode = "packet", out, dump, script;
+    float dt = 0.016f;
+    bool no_render = false;
     int W = 800, H = 600, frames = 10, device = -1;       // game.h:3-4
     bool have_pose = false;
     vec3 pos{0, 0, 0}, target{0, 0, -1};
@@ -29,6 +38,9 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--out")) { need(1); out = argv[++i]; }
         else if (!strcmp(argv[i], "--dump-scene")) { need(1); dump = argv[++i]; }
         else if (!strcmp(argv[i], "--device")) { need(1); device = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--script")) { need(1); script = argv[++i]; }
+        else if (!strcmp(argv[i], "--dt")) { need(1); dt = (float)atof(argv[++i]); }
+        else if (!strcmp(argv[i], "--no-render")) no_render = true;
         else if (!strcmp(argv[i], "--pos")) { need(3); pos = {(float)atof(argv[i + 1]), (float)atof(argv[i + 2]), (float)atof(argv[i + 3])}; i += 3; have_pose = true; }
         else if (!strcmp(argv[i], "--lookat")) { need(3); target = {(float)atof(argv[i + 1]), (float)atof(argv[i + 2]), (float)atof(argv[i + 3])}; i += 3; have_pose = true; }
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
@@ -42,29 +54,77 @@ int main(int argc, char** argv) {
         printf("scene %s: %zu meshes, %zu triangles, %zu textures\n", scene_file.c_str(), scene.meshList.size(), tris, scene.texList.size());
         if (!dump.empty()) { scene.SaveMRTS(dump); printf("wrote %s\n", dump.c_str()); return 0; }
 
+        // one entry per frame: the key held during that frame ("" = none)
+        std::vector<std::string> keys;
+        {
+            std::istringstream in(script);
+            std::string tok;
+            while (in >> tok) {
+                const size_t star = tok.find('*');
+                const int n = star == std::string::npos ? 1 : atoi(tok.c_str() + star + 1);
+                for (int k = 0; k < n; ++k) keys.push_back(tok.substr(0, star));
+            }
+        }
+        if (!keys.empty()) frames = (int)keys.size();
+
         Surface screen(W, H);                                   // template.cpp:98
         Camera camera;
-        if (have_pose) { camera.SetPosition(pos); camera.LookAt(target); }
+        vec3 position = {0, 0, 0};                              // game.cpp:4, 33
+        if (have_pose) { camera.SetPosition(pos); camera.LookAt(target); position = pos; }
+        std::vector<float> light = {0, 5, 0, 1, 1, 1, 1};       // raytracer.cpp:396-399
+        bool is_raytracer = mode != "raster";
         Raytracer raytracer;
-        raytracer.Init(&screen, device);                        // game.cpp:17-18
         auto t0 = std::chrono::steady_clock::now();
-        raytracer.BuildBVH(scene);                              // game.cpp:34
-        printf("BuildBVH + upload: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        if (!no_render) {
+            raytracer.Init(&screen, device);                    // game.cpp:17-18
+            raytracer.BuildBVH(scene);                          // game.cpp:34
+            printf("BuildBVH + upload: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+        auto add = [](vec3 a, vec3 b) { return vec3{a.x + b.x, a.y + b.y, a.z + b.z}; };
+        auto sub = [](vec3 a, vec3 b) { return vec3{a.x - b.x, a.y - b.y, a.z - b.z}; };
+        auto mul = [](vec3 a, float k) { return vec3{a.x * k, a.y * k, a.z * k}; };
 
         double total_ms = 0, best_ms = 1e30;
         uint64_t rays[4] = {0, 0, 0, 0};
         for (int f = 0; f < frames; ++f) {                      // Game::Tick
+            if (!keys.empty()) {                                // Game::HandleInput, game.cpp:41-75
+                const std::string& k = keys[f];
+                if (k == "SPACE") is_raytracer = !is_raytracer;
+                if (k == "W") position = add(position, mul(mul(camera.GetForward(), dt), 10.0f));
+                if (k == "S") position = sub(position, mul(mul(camera.GetForward(), dt), 10.0f));
+                if (k == "D") position = add(position, mul(mul(camera.GetRight(), dt), 10.0f));
+                if (k == "A") position = sub(position, mul(mul(camera.GetRight(), dt), 10.0f));
+                if (k == "R") position = add(position, mul(mul(camera.GetUp(), dt), 10.0f));
+                if (k == "F") position = sub(position, mul(mul(camera.GetUp(), dt), 10.0f));
+                camera.SetPosition(position);
+                const vec3 ahead = add(camera.GetPosition(), camera.GetForward());
+                if (k == "RIGHT") camera.LookAt(add(ahead, mul(camera.GetRight(), dt * 2.0f)));
+                if (k == "LEFT") camera.LookAt(sub(ahead, mul(camera.GetRight(), dt * 2.0f)));
+                if (k == "DOWN") camera.LookAt(add(ahead, mul(camera.GetUp(), dt * 2.0f)));
+                if (k == "UP") camera.LookAt(sub(ahead, mul(camera.GetUp(), dt * 2.0f)));
+                if (k == "O") light[1] += dt;
+                if (k == "P") light[1] -= dt;
+                if (!no_render && (k == "O" || k == "P")) raytracer.SetLights(light);
+            }
+            if (no_render) continue;
             screen.Clear(0);                                    // game.cpp:87
             t0 = std::chrono::steady_clock::now();
-            if (mode == "packet") raytracer.Render(camera);
+            if (!is_raytracer) raytracer.RenderRaster(camera);
             else if (mode == "recursive") raytracer.RenderRecursive(camera);
-            else if (mode == "raster") raytracer.RenderRaster(camera);
+            else if (mode == "packet" || mode == "raster") raytracer.Render(camera);
             else { fprintf(stderr, "unknown mode %s\n", mode.c_str()); return 2; }
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (f > 0 || frames == 1) { total_ms += ms; best_ms = ms < best_ms ? ms : best_ms; }
         }
+        if (!keys.empty()) {
+            printf("camera:");
+            for (int i = 0; i < 16; ++i) { uint32_t u; memcpy(&u, &camera.transform[i], 4); printf(" %08x", u); }
+            uint32_t lu; memcpy(&lu, &light[1], 4);
+            printf("\nlight.y: %08x  renderer: %s\n", lu, is_raytracer ? "raytracer" : "rasterizer");
+        }
+        if (no_render) return 0;
         const int counted = frames > 1 ? frames - 1 : 1;
-        if (mode != "raster") raytracer.RayCounts(rays);
+        if (is_raytracer) raytracer.RayCounts(rays);
         const double n_rays = (double)(rays[0] + rays[1] + rays[2]);
         printf("Frametime : %f ms (best %f), FPS : %.1f", total_ms / counted, best_ms, 1000.0 * counted / total_ms);
         if (n_rays > 0) printf(", %.0f rays/frame, %.1f Mrays/s (host framebuffer copy included)", n_rays, n_rays / best_ms / 1e3);

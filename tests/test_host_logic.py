@@ -196,3 +196,45 @@ def test_bvh_builder_under_sanitizers(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0, r.stdout[-500:] + r.stderr[-2000:]
     assert "trial 39" in r.stdout and "runtime error" not in r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="driver not built")
+def test_driver_input_script_follows_handle_input():
+    """The headless driver's --script replay of Game::HandleInput (game.cpp:41-75): camera matrix and light
+    position after a key sequence equal a float32 restatement that uses the oracle's glm-exact LookAt."""
+    import subprocess
+    script = "W*7 RIGHT*5 D*3 UP*4 R*2 LEFT*9 S*4 DOWN*3 F*1 A*6 O*11 P*4 SPACE*3"
+    dt = np.float32(0.0125)
+    r = subprocess.run([DRIVER, "--scene", os.path.join(ROOT, "tests", "golden", "maze.mrts"), "--no-render", "--script", script,
+                        "--dt", repr(float(dt)), "--pos", "1", "2", "3", "--lookat", "0", "0.5", "-4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got_cam = [int(x, 16) for x in r.stdout.split("camera:")[1].split("\n")[0].split()]
+    got_light = int(r.stdout.split("light.y:")[1].split()[0], 16)
+    f32 = np.float32
+    M = oracle_lib.lookat((1, 2, 3), (0, 0.5, -4)).astype(np.float32).copy()
+    pos = np.array([1, 2, 3], np.float32)
+    light, ray = f32(5), True
+    right, up, fwd, position = (lambda: M[0:3].copy()), (lambda: M[4:7].copy()), (lambda: -M[8:11]), (lambda: M[12:15].copy())
+    for tok in script.split():
+        k, n = tok.split("*")
+        for _ in range(int(n)):
+            if k == "SPACE":
+                ray = not ray
+            move = {"W": (fwd, 1), "S": (fwd, -1), "D": (right, 1), "A": (right, -1), "R": (up, 1), "F": (up, -1)}.get(k)
+            if move:
+                step = (move[0]() * dt) * f32(10.0)
+                pos = (pos + step if move[1] > 0 else pos - step).astype(np.float32)
+            M[12:15] = pos
+            ahead = (position() + fwd()).astype(np.float32)
+            turn = {"RIGHT": (right, 1), "LEFT": (right, -1), "DOWN": (up, 1), "UP": (up, -1)}.get(k)
+            if turn:
+                off = (turn[0]() * f32(dt * f32(2.0))).astype(np.float32)
+                target = ahead + off if turn[1] > 0 else ahead - off
+                M = oracle_lib.lookat(position(), target.astype(np.float32)).astype(np.float32).copy()
+            if k == "O":
+                light = f32(light + dt)
+            if k == "P":
+                light = f32(light - dt)
+    assert got_cam == [int(x) for x in M.view(np.uint32)]
+    assert got_light == int(np.array([light], np.float32).view(np.uint32)[0])
+    assert ("renderer: rasterizer" in r.stdout) == (not ray)
