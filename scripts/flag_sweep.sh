@@ -8,9 +8,10 @@ CS=raytracing_amd/csrc
 OUT=raytracing_amd/variants
 BASE="-std=c++17 -O3 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -w"
 declare -A V
-V[r4]=""
-V[r5]="-DMRT_RECURSIVE_WAVES=5"
-V[r6]="-DMRT_RECURSIVE_WAVES=6"
+V[x1]="-DMRT_XCD_RUN=1"
+V[x4]="-DMRT_XCD_RUN=4"
+V[x16]="-DMRT_XCD_RUN=16"
+V[x64]="-DMRT_XCD_RUN=64"
 if [ "${1:-}" = build ]; then
   mkdir -p $OUT
   make -C $CS -j8 >/dev/null
@@ -24,6 +25,6 @@ else
   for f in $OUT/libmrt_*.so; do
     n=$(basename $f .so); n=${n#libmrt_}
     echo "== $n"
-    MRT_LIB=$f timeout -k 10 100 python3 -u scripts/perf_probe.py ${PROBE_ARGS:-} 2>&1 | grep -v amdgpu.ids || exit 1
+    MRT_LIB=$f timeout -k 10 100 python3 -u scripts/${PROBE:-perf_probe.py} ${PROBE_ARGS:-} 2>&1 | grep -v amdgpu.ids | grep -E "${PROBE_GREP:-.}" || exit 1
   done
 fi
