@@ -180,6 +180,17 @@ class Workload:
         return self.fb[(self.i - 1) % len(self.fb)].cpu().numpy().view(np.uint32)
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def oracle_work_and_baseline(scene, W, H, mode, cam, threads, budget_s):
     """Runs the CPU oracle on the same frame: work counters (reference algorithm) and a timed baseline."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -258,7 +269,7 @@ def main():
             out["cpu_baseline"] = {"value": round(ora["rays"] / ora["best_s"] / 1e6, 3), "unit": "Mrays/s", "cores": threads,
                                    "kind": "port", "sample": "%d full 1920x1080 frames of the same workload, best frame "
                                    "(tile pool of %d threads, -O2 -ffp-contract=off)" % (ora["frames"], threads),
-                                   "ms_per_frame": round(ora["best_s"] * 1e3, 2)}
+                                   "ms_per_frame": round(ora["best_s"] * 1e3, 2), "cpu_model": cpu_model()}
             a8 = head.frame().view(np.uint8).reshape(-1, 4).astype(np.int16)
             b8 = ora["fb"].view(np.uint8).reshape(-1, 4).astype(np.int16)
             out["parity"] = {"pixels_beyond_1_255": float((np.abs(a8 - b8).max(axis=1) > 1).mean()),

@@ -867,9 +867,16 @@ static hipError_t launch_global_mode(const SceneDev& S, const FrameDev& F, hipSt
 template <int MODE>
 static hipError_t launch_resident_mode(const SceneDev& S, const FrameDev& F, int n_cus, hipStream_t stream) {
     const size_t lds = resident_lds_bytes(S.n_node_slots, S.n_tris, F.stack_entries);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_tiles_resident<MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    static bool lds_limit_raised[64] = {};          // per device, once: the attribute call is a driver round trip
+    if (dev < 0 || dev >= 64 || !lds_limit_raised[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_tiles_resident<MODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) lds_limit_raised[dev] = true;
+    }
     int threads = kResidentThreads;
     if (const char* e = getenv("MRT_RESIDENT_THREADS")) threads = std::max(64, std::min(kResidentThreads, atoi(e) / 64 * 64));   // tuning aid
     const int waves = threads / 64;
