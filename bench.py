@@ -25,6 +25,7 @@ Rank 0 prints one JSON line.  Besides the contract's keys it carries
   c4_8k_16spp   -- 7680x4320 with a 4x4 sample grid (packet path), the multi-GPU configuration:
                    ONE frame per step split over the ranks, measured at every N so its strong
                    scaling can be read from the same files;
+  c1_512_packet -- the reference's own 512x512 configuration, GPU and CPU;
   c3_1m_tris_4k -- synthetic 1,000,000-triangle soup at 3840x2160, packet path (scene in global
                    memory, divergent traversal);
   c5_raster_1m_4k -- the rasterizer path on the same soup (rank 0 only; host framebuffer copy
@@ -332,6 +333,18 @@ def main():
                 out["packet_path"]["roofline"] = {"bound": "valu", "achieved": round(ach, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                   "frac": round(ach / VALU_PEAK_TFLOPS, 4), "frac_of_unfused_issue_rate": round(ach / VALU_UNFUSED_TOPS, 4)}
         del pk
+        c1 = Workload("c1", scene, 512, 512, MODE_PACKET, 1, cam, rank, world, torch, dist)
+        r1 = c1.run(args.steps, args.warmup)
+        out["c1_512_packet"] = {"workload": "same scene, 512x512, 64-ray packets + shadow rays: the reference's own CPU-runnable configuration",
+                                "value": round(r1["mrays_per_s"], 3), "unit": "Mrays/s", "ms_per_step": round(r1["ms_per_step"], 5),
+                                "kernel_ms": round(r1["kernel_ms"], 5), "rays_per_frame": r1["rays_per_step"]}
+        if not args.no_cpu:
+            o1 = oracle_work_and_baseline(scene, 512, 512, MODE_PACKET, cam, threads, 2.0)
+            out["c1_512_packet"]["cpu_value"] = round(o1["rays"] / o1["best_s"] / 1e6, 3)
+            out["c1_512_packet"]["cpu_ms_per_frame"] = round(o1["best_s"] * 1e3, 3)
+            out["c1_512_packet"]["cpu_cores"] = threads
+            assert o1["rays"] == r1["rays_per_step"] and np.array_equal(c1.frame(), o1["fb"])
+        del c1
         soup = scene_io.soup_scene(1000000)
         c3 = Workload("c3", soup, 3840, 2160, MODE_PACKET, 1, cam, rank, world, torch, dist)
         r3 = c3.run(max(2, min(args.steps, 10)), 2)
