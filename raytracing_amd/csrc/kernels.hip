@@ -163,6 +163,29 @@ __device__ __forceinline__ void slab_div_pair(v4f l0, v4f l1, v4f r0, v4f r1, co
     rightN = slab_pass(tNear2, tFar2, t);
 }
 
+// The two child tests of a shadow ray (t = INFINITY, so `tNear < t` always holds) decided from
+// interval bounds, for rays and scenes inside the ranges of the exact-division shortcut.
+// q~ = a * RN(1/d) and the reference's q = RN(a / d) are within 2^-23 resp. 2^-24 of a/d
+// relatively, so |q - q~| <= 2^-22 |q~|, and zero and sign are preserved exactly.  g(x) = x - e|x|
+// and h(x) = x + e|x| are increasing and commute with min and max, so the reference's tNear lies in
+// [g(tNear~), h(tNear~)] and its tFar in [g(tFar~), h(tFar~)] (e = 2^-21 leaves room for the
+// rounding of g and h themselves), and tFar > 0 iff tFar~ > 0.  Returns false for a lane whose
+// `tFar >= tNear` falls inside the bounds; the caller then evaluates slab_div_pair for the wave.
+__device__ __forceinline__ bool slab_pair_shadow_interval(v4f l0, v4f l1, v4f r0, v4f r1, const RayDiv& R, bool& leftN, bool& rightN) {
+    constexpr float e = 0x1p-21f;
+    float nL, fL, nR, fR;
+    slab_terms_finite((xyz(l0) - R.O) * R.r, (xyz(l1) - R.O) * R.r, nL, fL);
+    slab_terms_finite((xyz(r0) - R.O) * R.r, (xyz(r1) - R.O) * R.r, nR, fR);
+    const float nLlo = __builtin_fmaf(-e, fabsf(nL), nL), nLhi = __builtin_fmaf(e, fabsf(nL), nL);
+    const float fLlo = __builtin_fmaf(-e, fabsf(fL), fL), fLhi = __builtin_fmaf(e, fabsf(fL), fL);
+    const float nRlo = __builtin_fmaf(-e, fabsf(nR), nR), nRhi = __builtin_fmaf(e, fabsf(nR), nR);
+    const float fRlo = __builtin_fmaf(-e, fabsf(fR), fR), fRhi = __builtin_fmaf(e, fabsf(fR), fR);
+    leftN = (fLlo >= nLhi) && (fL > 0.0f);
+    rightN = (fRlo >= nRhi) && (fR > 0.0f);
+    const bool l_no = (fLhi < nLlo) || !(fL > 0.0f), r_no = (fRhi < nRlo) || !(fR > 0.0f);
+    return (leftN || l_no) && (rightN || r_no);
+}
+
 // ---------------------------------------------------------------------------------------
 // Ray/triangle: Triangle::Intersect / Intersect2 (raytracer.cpp:287-356).
 // WAVE_REJECT: the lanes calling this test the SAME triangle (packet leaves, shared shadow
@@ -448,8 +471,12 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
             const v4f l0 = sc.node(2 * L), l1 = sc.node(2 * L + 1), r0 = sc.node(2 * Rr), r1 = sc.node(2 * Rr + 1);
             MRT_TICK(wd, 4);
             bool leftN, rightN;
-            float a, b;
-            slab_div_pair(l0, l1, r0, r1, R, shortcut, INFINITY, leftN, rightN, a, b);
+            const bool sure = shortcut && slab_pair_shadow_interval(l0, l1, r0, r1, R, leftN, rightN);
+            if (__any(((m >> lane) & 1ull) && !sure)) {
+                MRT_TICK(wd, 15);
+                float a, b;
+                slab_div_pair(l0, l1, r0, r1, R, shortcut, INFINITY, leftN, rightN, a, b);
+            }
             const unsigned long long ml = __ballot(leftN) & m, mr = __ballot(rightN) & m;
             if (mr) work.push(lane, Rr, mr);
             if (ml) work.push(lane, L, ml);

@@ -38,6 +38,15 @@ int main(int argc, char** argv) {
             if (bad < 5) printf("a=%a d=%a want=%a got=%a\n", a, d, want, got);
             ++bad;
         }
+        // the bound the interval form of the shadow rays' box test rests on (kernels.hip,
+        // slab_pair_shadow_interval): the one-multiply estimate a * RN(1/d) is within 2^-22 of the
+        // exact quotient relatively, has its sign, and is zero exactly when it is
+        const float est = a * r;
+        const double err = (double)want - (double)est, lim = 0x1p-22 * (est < 0 ? -(double)est : (double)est);
+        if ((err < 0 ? -err : err) > lim || (want == 0.0f) != (est == 0.0f) || (want < 0.0f) != (est < 0.0f)) {
+            if (bad < 5) printf("estimate: a=%a d=%a want=%a est=%a\n", a, d, want, est);
+            ++bad;
+        }
     }
     // range predicates
     if (mrt::div_shortcut_dir_ok(0.0f) || mrt::div_shortcut_dir_ok(mk(0, 0, 0x7fffffu)) || mrt::div_shortcut_dir_ok(1e-20f) ||
