@@ -360,6 +360,32 @@ def test_root_gate_quirk_on_gpu(maze_scene, known):
     rt.close()
 
 
+def test_context_lifecycle_releases_device_memory(maze_scene):
+    """Creating, using (both ray modes, rasterizer, operators) and destroying contexts over and over leaves
+    device memory where it was."""
+    import torch
+    torch.cuda.synchronize()
+
+    def cycle():
+        rt = Raytracer(256, 128, device=0)
+        rt.build_bvh(maze_scene)
+        rt.render(oracle_lib.IDENTITY, mode=MODE_PACKET)
+        rt.render(oracle_lib.IDENTITY, mode=MODE_RECURSIVE, spp_grid=2)
+        rt.raster(oracle_lib.IDENTITY)
+        O = np.zeros((64, 3), np.float32)
+        D = np.tile(np.float32([0, 0, -1]), (64, 1))
+        rt.trace_rays(O, D, np.full(64, 1e8, np.float32))
+        rt.close()
+
+    for _ in range(3):
+        cycle()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        cycle()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, "device memory shrank by %d bytes over 20 context lifetimes" % (free0 - free1)
+
+
 def test_error_paths(maze_scene):
     rt = Raytracer(64, 64, device=0)
     with pytest.raises(MrtError, match="scene_upload"):
