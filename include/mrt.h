@@ -118,7 +118,9 @@ void mrt_host_free(void* p);
  * of 8) into DEVICE memory fb_dev (row y at fb_dev + y*pitch_px) on `stream` (a hipStream_t,
  * NULL = the default stream) and returns without synchronising.  This is the launch the
  * tile scheduler of threads.cpp:158-169 / raytracer.cpp:436-457 is replaced by; a multi-GPU
- * caller gives each rank its own row band.  hit_ids_dev optional (device, full-frame indexing). */
+ * caller gives each rank its own row band.  hit_ids_dev optional (device, full-frame indexing).
+ * Launches of one context share its tile queues and counters: a launch on another stream than
+ * the previous one first waits (on the device) for that one to finish. */
 int mrt_render_device(mrt_ctx* ctx, const float cam_to_world[16], uint32_t flags,
                       int y_begin, int y_end, void* fb_dev, int pitch_px,
                       void* hit_ids_dev, void* stream);

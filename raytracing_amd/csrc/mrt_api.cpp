@@ -73,6 +73,8 @@ struct mrt_ctx {
     DevBuf<int32_t> d_ids;
     DevBuf<unsigned long long> d_counters;
     hipStream_t last_stream = nullptr;
+    hipEvent_t last_done = nullptr;   // recorded after every frame launch: the context's counters and queues are shared,
+    bool launched = false;            // so a launch on another stream first waits for the previous one
     // page-locked staging for the synchronous entry point: device -> pinned at PCIe rate, then a host copy
     void* h_stage = nullptr;
     size_t h_stage_bytes = 0;
@@ -169,6 +171,7 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
     F.counters = c->d_counters.p;
     F.stack_entries = c->stack_entries;
     F.stats = getenv("MRT_NO_STATS") ? 0 : 1;
+    if (c->launched && stream != c->last_stream) MRT_HIP(c, hipStreamWaitEvent(stream, c->last_done, 0));
     MRT_HIP(c, hipMemsetAsync(c->d_counters.p, 0, kCounterSlots * sizeof(unsigned long long), stream));
     // The LDS-resident kernel pays off for the recursive shader, whose per-lane traversal reads a
     // different node or triangle in every lane.  The packet path reads wave-uniform data (scalar
@@ -176,7 +179,9 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
     bool resident = c->resident && mode == (int)MRT_MODE_RECURSIVE;
     if (const char* e = getenv("MRT_RESIDENT_PACKET")) resident = c->resident && atoi(e) != 0;   // tuning aid
     MRT_HIP(c, launch_render(c->scene, F, mode, resident, c->n_cus, stream));
+    MRT_HIP(c, hipEventRecord(c->last_done, stream));
     c->last_stream = stream;
+    c->launched = true;
     return MRT_OK;
 }
 
@@ -202,12 +207,16 @@ int mrt_create(int width, int height, int device, mrt_ctx** out) {
     mrt_ctx* c = new mrt_ctx();
     c->width = width; c->height = height; c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->last_done, hipEventDisableTiming);
     if (e == hipSuccess) e = c->d_counters.ensure(kCounterSlots);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess) c->n_cus = prop.multiProcessorCount;
     if (e != hipSuccess) {
         std::string msg = std::string("context set-up: ") + hipGetErrorString(e);
+        if (c->last_done) (void)hipEventDestroy(c->last_done);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        c->d_counters.release();
         delete c;
         return fail(nullptr, MRT_E_HIP, msg);
     }
@@ -227,6 +236,7 @@ void mrt_destroy(mrt_ctx* c) {
     c->d_fb.release(); c->d_ids.release(); c->d_counters.release();
     raster_release(c->raster);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->last_done) (void)hipEventDestroy(c->last_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

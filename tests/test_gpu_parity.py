@@ -386,6 +386,28 @@ def test_context_lifecycle_releases_device_memory(maze_scene):
     assert free0 - free1 < 8 << 20, "device memory shrank by %d bytes over 20 context lifetimes" % (free0 - free1)
 
 
+def test_launches_on_two_streams_do_not_disturb_each_other(maze_scene):
+    """Frames of one context launched back to back on different streams: the context's tile queues and
+    counters are shared, so the library orders the launches itself; both frames come out right."""
+    import torch
+    W, H = 512, 256
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(maze_scene)
+    cams = [pose_cam(POSES[1]), pose_cam(POSES[2])]
+    refs = [rt.render(c, mode=MODE_RECURSIVE)[0] for c in cams]
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    fa = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
+    fb = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    for _ in range(5):
+        rt.render_device(cams[0], fa.data_ptr(), W, mode=MODE_RECURSIVE, stream=sa.cuda_stream)
+        rt.render_device(cams[1], fb.data_ptr(), W, mode=MODE_RECURSIVE, stream=sb.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(fa.cpu().numpy().view(np.uint32), refs[0])
+    assert np.array_equal(fb.cpu().numpy().view(np.uint32), refs[1])
+    rt.close()
+
+
 def test_error_paths(maze_scene):
     rt = Raytracer(64, 64, device=0)
     with pytest.raises(MrtError, match="scene_upload"):
