@@ -42,7 +42,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOPS_SLAB, FLOPS_TRI = 25, 59              # per test, from the reference source
+# operations of one test as the reference source writes them: slab test raytracer.cpp:1227-1237 (6 sub, 6 mul or div,
+# 10 min/max, 3 compares), triangle test raytracer.cpp:287-321 on its full path
+FLOPS_SLAB, FLOPS_TRI = 25, 59
 FLOPS_FIXED_PRIMARY, FLOPS_FIXED_SECONDARY = 40, 30
 VALU_PEAK_TFLOPS = 157.3                    # fp32 vector peak of the part; counts every lane-operation as a fused multiply-add
 VALU_UNFUSED_TOPS = 157.3 / 2               # the same issue rate with ONE flop per lane-operation (256 CUs x 128 lanes/clk x 2.4 GHz):
