@@ -1,6 +1,14 @@
 #include "bvh_builder.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 namespace mrt {
 
@@ -49,6 +57,7 @@ namespace {
 
 struct KeyIdx { float key; uint32_t idx; };
 struct Box { float lo[3], hi[3]; };
+struct Span { int s, e; };
 
 // Surface-area measure of raytracer.h:303-307: (dz*dx + dz*dy + dx*dy) * 2
 inline float area(const Box& b) {
@@ -86,7 +95,7 @@ public:
     // outer loop stops at L == R without looking at that element, which then belongs to BOTH
     // sub-ranges; the permutation among equal keys therefore depends on sorting [start,R]
     // completely before [L,end].  The work list is LIFO, so the right range is pushed first.
-    void sort_axis(int axis, int start, int end) {
+    void sort_axis(int axis, int start, int end, std::vector<Span>& work) {
         const float* key = cen[axis].data();
         for (int i = start; i <= end; ++i) scratch[i] = {key[B.idx[i]], B.idx[i]};
         work.clear();
@@ -113,8 +122,8 @@ public:
     // beyond the plane" advances monotonically and the left/right bounds of every candidate are
     // one forward and one backward accumulation.
     void sweep_axis(int axis, uint32_t first, uint32_t count, float lo_axis, float extent,
-                    float& best_cost, int& best_axis, int& split_out) {
-        sort_axis(axis, (int)first, (int)(first + count - 1));
+                    float& best_cost, int& best_axis, int& split_out, std::vector<Span>& work) {
+        sort_axis(axis, (int)first, (int)(first + count - 1), work);
         const float step = extent / 10.0f;
         float plane = step + lo_axis;
         plane += step;
@@ -166,6 +175,12 @@ public:
         split_out = best_split;
     }
 
+    // The tree is built as linked nodes first and numbered afterwards.  A node's split only touches its
+    // own range of the index array, so the two children of a split are independent pieces of work: large
+    // ones are handed to a pool of threads, small ones are finished by the thread that made them.  The
+    // reference numbers nodes in the order its recursion allocates them (children pair first, then the
+    // whole left subtree, then the right one; raytracer.cpp:1181-1199), which number_nodes reproduces,
+    // so the arrays are the same whatever the threads did in which order.
     void run() {
         B.n_tris = (uint32_t)B.tris.size();
         B.n_nodes_alloc = B.n_tris * 2 + 1;
@@ -181,46 +196,121 @@ public:
         B.first[0] = 0;
         B.count[0] = B.n_tris;
         if (B.n_tris == 0) return;
-        struct Todo { uint32_t node; int depth; };
-        std::vector<Todo> todo;
-        todo.push_back({0, 0});
-        while (!todo.empty()) {
-            const Todo cur = todo.back();
-            todo.pop_back();
-            uint32_t left, right;
-            if (split_node(cur.node, cur.depth, left, right)) {
-                todo.push_back({right, cur.depth + 1});   // left subtree is finished first, as the recursion does
-                todo.push_back({left, cur.depth + 1});
+
+        int n_threads = 1;
+        if (B.n_tris >= 4 * kTaskMin) {
+            n_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+            if (const char* e = getenv("MRT_BUILD_THREADS")) n_threads = std::max(1, std::min(64, atoi(e)));
+        }
+        std::vector<std::unique_ptr<Worker>> workers;
+        for (int i = 0; i < n_threads; ++i) workers.emplace_back(new Worker());
+        TNode root;
+        root.first = 0; root.count = B.n_tris; root.depth = 0;
+        pending = 1;
+        queue.push_back(&root);
+        std::vector<std::thread> threads;
+        for (int i = 1; i < n_threads; ++i) threads.emplace_back([this, &workers, i] { work_loop(*workers[i]); });
+        work_loop(*workers[0]);
+        for (std::thread& t : threads) t.join();
+
+        // number the nodes in the reference's allocation order and write the arrays
+        std::vector<std::pair<const TNode*, uint32_t>> st;
+        st.push_back({&root, 0u});
+        while (!st.empty()) {
+            const auto [n, slot] = st.back();
+            st.pop_back();
+            B.max_depth = std::max(B.max_depth, n->depth);
+            B.nmin[slot] = {n->box.lo[0], n->box.lo[1], n->box.lo[2]};
+            B.nmax[slot] = {n->box.hi[0], n->box.hi[1], n->box.hi[2]};
+            if (n->left) {
+                B.pool_ptr += 2;
+                const uint32_t l = B.pool_ptr - 1, r = B.pool_ptr;
+                B.first[slot] = l;
+                B.count[slot] = 0;
+                st.push_back({n->right, r});      // the left subtree is numbered completely before the right one
+                st.push_back({n->left, l});
+            } else {
+                B.first[slot] = n->first;
+                B.count[slot] = n->count;
             }
         }
     }
 
 private:
-    bool split_node(uint32_t self, int depth, uint32_t& left, uint32_t& right) {
-        B.max_depth = std::max(B.max_depth, depth);
-        const uint32_t first = B.first[self], count = B.count[self];
+    static constexpr uint32_t kTaskMin = 8192;     // ranges at least this long are offered to other threads
+
+    struct TNode {
+        Box box;
+        uint32_t first = 0, count = 0;
+        int depth = 0;
+        TNode* left = nullptr;
+        TNode* right = nullptr;
+    };
+    struct Worker {
+        std::deque<TNode> arena;                   // deque: growing never moves a node
+        std::vector<Span> sort_work;
+        std::vector<TNode*> local;
+    };
+
+    void work_loop(Worker& w) {
+        for (;;) {
+            TNode* n = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [this] { return !queue.empty() || pending == 0; });
+                if (queue.empty()) return;          // pending == 0: the tree is complete
+                n = queue.back();
+                queue.pop_back();
+            }
+            // finish this node and everything below it that is too small to share
+            w.local.clear();
+            w.local.push_back(n);
+            while (!w.local.empty()) {
+                TNode* cur = w.local.back();
+                w.local.pop_back();
+                if (!split_node(*cur, w)) continue;
+                for (TNode* c : {cur->right, cur->left}) {
+                    if (c->count >= kTaskMin) {
+                        std::lock_guard<std::mutex> lk(mu);
+                        ++pending;
+                        queue.push_back(c);
+                        cv.notify_one();
+                    } else {
+                        w.local.push_back(c);
+                    }
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cv.notify_all();
+            }
+        }
+    }
+
+    bool split_node(TNode& self, Worker& w) {
+        const uint32_t first = self.first, count = self.count;
         const Box nb = bounds_forward(first, count);
-        B.nmin[self] = {nb.lo[0], nb.lo[1], nb.lo[2]};
-        B.nmax[self] = {nb.hi[0], nb.hi[1], nb.hi[2]};
+        self.box = nb;
         if (count < 3) return false;          // primPerNode (raytracer.h:353)
-        B.pool_ptr += 2;
-        left = B.pool_ptr - 1;
-        right = B.pool_ptr;
         const float init_cost = area(nb) * count;
         float best_cost = init_cost;
         int best_axis = 0;
         int split[3] = {0, 0, 0};
         for (int axis = 0; axis < 3; ++axis)
-            sweep_axis(axis, first, count, nb.lo[axis], nb.hi[axis] - nb.lo[axis], best_cost, best_axis, split[axis]);
-        sort_axis(best_axis, (int)first, (int)(first + count - 1));     // raytracer.cpp:1165-1179
-        if (init_cost == best_cost) { B.pool_ptr -= 2; return false; }
+            sweep_axis(axis, first, count, nb.lo[axis], nb.hi[axis] - nb.lo[axis], best_cost, best_axis, split[axis], w.sort_work);
+        sort_axis(best_axis, (int)first, (int)(first + count - 1), w.sort_work);     // raytracer.cpp:1165-1179
+        if (init_cost == best_cost) return false;
         const uint32_t left_count = (uint32_t)(split[best_axis] - (int)first);
         const uint32_t right_count = count - left_count;
-        if (left_count == 0 || right_count == 0) { B.pool_ptr -= 2; return false; }
-        B.first[left] = first;                   B.count[left] = left_count;
-        B.first[right] = (uint32_t)split[best_axis]; B.count[right] = right_count;
-        B.first[self] = left;
-        B.count[self] = 0;
+        if (left_count == 0 || right_count == 0) return false;
+        w.arena.emplace_back();
+        TNode* l = &w.arena.back();
+        w.arena.emplace_back();
+        TNode* r = &w.arena.back();
+        l->first = first;                        l->count = left_count;  l->depth = self.depth + 1;
+        r->first = (uint32_t)split[best_axis];   r->count = right_count; r->depth = self.depth + 1;
+        self.left = l;
+        self.right = r;
         return true;
     }
 
@@ -239,9 +329,11 @@ private:
 
     HostBVH& B;
     std::vector<float> cen[3], tlo[3], thi[3];
-    std::vector<KeyIdx> scratch;
-    struct Span { int s, e; };
-    std::vector<Span> work;
+    std::vector<KeyIdx> scratch;               // indexed like B.idx: concurrent nodes use disjoint parts
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<TNode*> queue;                 // nodes waiting for a thread
+    size_t pending = 0;                        // queued + being worked on
 };
 
 }  // namespace

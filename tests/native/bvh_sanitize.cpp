@@ -5,11 +5,12 @@
 #include <cstdlib>
 #include <cmath>
 using namespace mrt;
-int main() {
+int main(int argc, char** argv) {
+    const bool big = argc > 1;      // one scene large enough for the builder to use its thread pool (run under TSan)
     unsigned s = 1;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
-    for (int trial = 0; trial < 40; ++trial) {
-        int n = trial < 5 ? trial : (int)(rnd() * 3000) + 1;
+    for (int trial = 0; trial < (big ? 2 : 40); ++trial) {
+        int n = big ? 90000 : (trial < 5 ? trial : (int)(rnd() * 3000) + 1);
         std::vector<float> pos(9 * n), uv(6 * n, 0.5f), N(3 * n, 0.0f);
         std::vector<int32_t> tri(3 * n);
         for (int i = 0; i < n; ++i) {
