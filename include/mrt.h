@@ -108,8 +108,8 @@ int mrt_render(mrt_ctx* ctx, const float cam_to_world[16], uint32_t flags,
 
 /* Optional: page-locked host memory for the caller's Surface (the reference allocates its pixel
  * buffer with a 64-byte aligned malloc, surface.cpp:114-120 / template.cpp:98).  mrt_render
- * recognises a framebuffer that lies in such memory and lets the GPU write the frame straight
- * into it; any other host pointer goes through an internal page-locked staging buffer and one
+ * recognises a framebuffer that lies in such memory and lets the kernel write the frame straight
+ * into it (the transfer then runs under the rendering); any other host pointer goes through an internal page-locked staging buffer and one
  * extra memcpy.  Returns NULL when no GPU is present or memory is short. */
 void* mrt_host_alloc(size_t bytes);
 void mrt_host_free(void* p);

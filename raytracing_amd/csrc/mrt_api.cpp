@@ -396,15 +396,24 @@ int mrt_render(mrt_ctx* c, const float cam[16], uint32_t flags, uint32_t* fb, in
     const size_t npx = (size_t)c->width * c->height;
     MRT_HIP(c, c->d_fb.ensure(npx));
     if (hit_ids) MRT_HIP(c, c->d_ids.ensure(npx * g * g));
-    if (int rc = render_common(c, cam, flags, 0, c->height, c->d_fb.p, c->width, hit_ids ? c->d_ids.p : nullptr, c->stream))
-        return rc;
-    // a framebuffer in page-locked memory (mrt_host_alloc, or registered by the caller) is written directly
+    // a framebuffer in page-locked memory (mrt_host_alloc, or registered by the caller) is written by the
+    // kernel itself through its device address, so the transfer over PCIe runs under the rendering
     bool direct = false;
+    uint32_t* fb_target = c->d_fb.p;
+    int fb_pitch = c->width;
     {
         hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, fb) == hipSuccess) direct = at.type == hipMemoryTypeHost;
-        else (void)hipGetLastError();
+        void* dp = nullptr;
+        if (hipPointerGetAttributes(&at, fb) == hipSuccess && at.type == hipMemoryTypeHost &&
+            hipHostGetDevicePointer(&dp, fb, 0) == hipSuccess && dp && !getenv("MRT_NO_DIRECT_HOST")) {
+            direct = true;
+            fb_target = static_cast<uint32_t*>(dp);
+            fb_pitch = pitch_px;
+        }
+        (void)hipGetLastError();
     }
+    if (int rc = render_common(c, cam, flags, 0, c->height, fb_target, fb_pitch, hit_ids ? c->d_ids.p : nullptr, c->stream))
+        return rc;
     const size_t fb_bytes = direct ? 0 : npx * 4, id_bytes = hit_ids ? npx * g * g * sizeof(int32_t) : 0, need = fb_bytes + id_bytes + 64;
     if (c->h_stage_bytes < need) {
         if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -414,11 +423,7 @@ int mrt_render(mrt_ctx* c, const float cam[16], uint32_t flags, uint32_t* fb, in
     }
     unsigned char* stage = static_cast<unsigned char*>(c->h_stage);
     unsigned long long* wd_stage = reinterpret_cast<unsigned long long*>(stage + fb_bytes + id_bytes);
-    if (direct)
-        MRT_HIP(c, hipMemcpy2DAsync(fb, (size_t)pitch_px * 4, c->d_fb.p, (size_t)c->width * 4, (size_t)c->width * 4, c->height,
-                                    hipMemcpyDeviceToHost, c->stream));
-    else
-        MRT_HIP(c, hipMemcpyAsync(stage, c->d_fb.p, fb_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (!direct) MRT_HIP(c, hipMemcpyAsync(stage, c->d_fb.p, fb_bytes, hipMemcpyDeviceToHost, c->stream));
     if (hit_ids) MRT_HIP(c, hipMemcpyAsync(stage + fb_bytes, c->d_ids.p, id_bytes, hipMemcpyDeviceToHost, c->stream));
     MRT_HIP(c, hipMemcpyAsync(wd_stage, c->d_counters.p + 5, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     MRT_HIP(c, hipStreamSynchronize(c->stream));
