@@ -12,8 +12,10 @@
 //   occluded_wave     shadow rays of one wave traced together: the reference only uses
 //                     "was anything hit", which does not depend on visiting order, so the 64
 //                     rays share one work list and each lane keeps its own activity bit.
-// Scene data comes either from global memory (any size; wave-uniform reads become scalar
-// loads) or from an LDS copy held by a persistent 16-wave workgroup (small scenes).
+// Scene data comes either from global memory (render_tiles_global: any size, one wave per tile,
+// wave-uniform reads become scalar loads; used for the packet path and for large scenes) or
+// from an LDS copy held by a persistent 16-wave workgroup (render_tiles_resident: recursive
+// shader on scenes that fit, whose per-lane traversal reads a different address in every lane).
 //
 // All arithmetic that decides a hit or a colour follows the reference's operation order;
 // this file must be compiled with -ffp-contract=off and without fast-math.
