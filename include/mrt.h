@@ -83,6 +83,14 @@ int  mrt_version(void);
 int mrt_scene_upload(mrt_ctx* ctx, const mrt_mesh* meshes, int n_meshes,
                      const mrt_texture* textures, int n_textures);
 
+/* Same call with the acceleration structure built on the GPU (Morton order + binary radix tree)
+ * instead of by the reference's builder (raytracer.cpp:897-1203): milliseconds instead of seconds
+ * for large scenes, e.g. per frame for moving geometry.  The nearest distances found are the same;
+ * the reported triangle may be the other one of two hit at exactly the same distance, because that
+ * choice follows the reference tree's leaf order.  Not for bit-exact comparison with the reference. */
+int mrt_scene_upload_lbvh(mrt_ctx* ctx, const mrt_mesh* meshes, int n_meshes,
+                          const mrt_texture* textures, int n_textures);
+
 /* Raytracer::m_Lights (raytracer.h:244; game.cpp:69-70 moves light 0): n records of
  * {pos.xyz, colour.xyzw} = 7 floats, colour in the reference's x=A,y=R,z=G,w=B order. */
 int mrt_set_lights(mrt_ctx* ctx, const float* pos_rgba7, int n);

@@ -17,7 +17,8 @@ LIB_PATH = os.environ.get("MRT_LIB") or os.path.join(_HERE, "libmrt.so")     # M
 MODE_PACKET = 0
 MODE_RECURSIVE = 1
 
-SYMBOLS = ("mrt_create", "mrt_destroy", "mrt_last_error", "mrt_version", "mrt_scene_upload", "mrt_set_lights",
+SYMBOLS = ("mrt_create", "mrt_destroy", "mrt_last_error", "mrt_version", "mrt_scene_upload", "mrt_scene_upload_lbvh",
+           "mrt_set_lights",
            "mrt_bvh_build_host", "mrt_render", "mrt_host_alloc", "mrt_host_free", "mrt_render_device", "mrt_render_device_part", "mrt_part_rows",
            "mrt_raster_render", "mrt_trace_packets",
            "mrt_trace_rays", "mrt_get_ray_counts", "mrt_camera_look_at")
@@ -71,6 +72,7 @@ def lib():
         L.mrt_last_error.argtypes = [vp]
         L.mrt_last_error.restype = C.c_char_p
         L.mrt_scene_upload.argtypes = [vp, C.POINTER(_Mesh), i32, C.POINTER(_Texture), i32]
+        L.mrt_scene_upload_lbvh.argtypes = [vp, C.POINTER(_Mesh), i32, C.POINTER(_Texture), i32]
         L.mrt_set_lights.argtypes = [vp, vp, i32]
         L.mrt_bvh_build_host.argtypes = [C.POINTER(_Mesh), i32, vp, vp, vp, vp]
         L.mrt_render.argtypes = [vp, vp, C.c_uint32, vp, i32, vp]
@@ -200,11 +202,13 @@ class Raytracer:
         if rc != 0:
             raise MrtError("%s failed (%d): %s" % (what, rc, self.L.mrt_last_error(self.h).decode()))
 
-    def build_bvh(self, scene):
-        """Raytracer::BuildBVH(meshList): flatten, build, upload."""
+    def build_bvh(self, scene, lbvh=False):
+        """Raytracer::BuildBVH(meshList): flatten, build, upload.  lbvh=True: GPU-built linear BVH instead
+        of the reference's tree (fast, same distances, tie-breaks may differ)."""
         meshes, textures, keep = _pack_scene(scene)
-        self._check(self.L.mrt_scene_upload(self.h, meshes, len(scene["meshes"]), textures, len(scene["textures"])),
-                    "mrt_scene_upload")
+        fn = self.L.mrt_scene_upload_lbvh if lbvh else self.L.mrt_scene_upload
+        self._check(fn(self.h, meshes, len(scene["meshes"]), textures, len(scene["textures"])),
+                    "mrt_scene_upload_lbvh" if lbvh else "mrt_scene_upload")
         del keep
 
     def set_lights(self, lights):

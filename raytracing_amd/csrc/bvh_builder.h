@@ -5,6 +5,7 @@
 // traversals depend on it.  Reference: raytracer.cpp:897-1203 (BVH::BVH, BVHNode::Subdivide,
 // SortX/Y/Z), raytracer.h:154-172 (Triangle constructor), raytracer.h:251-308 (AABB).
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include <string>
@@ -38,5 +39,8 @@ bool flatten_meshes(const mrt_mesh* meshes, int n_meshes, int n_textures, bool n
                     std::vector<HostTri>& out, std::string& err);
 
 void build_bvh(HostBVH& bvh);
+
+// lbvh.hip: a linear BVH built on the current GPU instead (not the reference's tree; see there).
+bool build_lbvh_device(HostBVH& bvh, hipStream_t stream, std::string& err);
 
 }  // namespace mrt

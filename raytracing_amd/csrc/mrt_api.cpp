@@ -257,7 +257,17 @@ int mrt_set_lights(mrt_ctx* c, const float* pos_rgba7, int n) {
     return MRT_OK;
 }
 
+static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures, bool lbvh);
+
 int mrt_scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures) {
+    return scene_upload(c, meshes, n_meshes, textures, n_textures, false);
+}
+
+int mrt_scene_upload_lbvh(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures) {
+    return scene_upload(c, meshes, n_meshes, textures, n_textures, true);
+}
+
+static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures, bool lbvh) {
     if (!c) return MRT_E_ARG;
     if (n_textures < 0 || (n_textures > 0 && !textures)) return fail(c, MRT_E_ARG, "bad texture array");
     for (int i = 0; i < n_textures; ++i)
@@ -267,7 +277,11 @@ int mrt_scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt
     std::string err;
     c->has_scene = false;
     if (!flatten_meshes(meshes, n_meshes, n_textures, true, c->bvh.tris, err)) return fail(c, MRT_E_ARG, err);
-    build_bvh(c->bvh);
+    if (lbvh && !c->bvh.tris.empty()) {
+        if (!build_lbvh_device(c->bvh, c->stream, err)) return fail(c, MRT_E_HIP, err);
+    } else {
+        build_bvh(c->bvh);
+    }
     const HostBVH& B = c->bvh;
     if (B.max_depth + 2 > kStackDepth) return fail(c, MRT_E_LIMIT, "BVH deeper than the traversal stack (62 levels)");
     if (B.pool_ptr >= (1u << 26)) return fail(c, MRT_E_LIMIT, "too many BVH nodes for the packet work list encoding");

@@ -1,0 +1,76 @@
+"""The GPU-built linear BVH (mrt_scene_upload_lbvh) is an alternative acceleration structure, not the
+reference's tree: nearest distances must be those of the reference tree bit for bit, triangle IDs may
+only differ where two triangles are hit at exactly the same distance."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from conftest import POSES, pose_cam
+from raytracing_amd import MODE_PACKET, MODE_RECURSIVE, Raytracer, scene_io
+
+pytestmark = pytest.mark.gpu
+
+
+def _primary_packets(cam, W, H):
+    """Primary rays of a frame in tile order, as (packets, 64, 3) arrays, made by the oracle's ray generator."""
+    o = oracle_lib.Oracle()
+    D = np.zeros((H, W, 3), np.float32)
+    rD = np.zeros((H, W, 3), np.float32)
+    for y in range(H):
+        for x in range(W):
+            D[y, x], rD[y, x] = o.gen_ray(cam, W, H, x, y)
+    def tiles(a):
+        return a.reshape(H // 8, 8, W // 8, 8, 3).transpose(0, 2, 1, 3, 4).reshape(-1, 64, 3).copy()
+    O = np.broadcast_to(np.asarray(cam[12:15], np.float32), (H, W, 3)).copy()
+    return tiles(O), tiles(D), tiles(rD)
+
+
+@pytest.mark.parametrize("scene_name", ["maze", "soup"])
+def test_lbvh_gives_the_same_nearest_hits(maze_scene, scene_name):
+    scene = maze_scene if scene_name == "maze" else scene_io.soup_scene(20000)
+    W, H = 128, 64
+    ref = Raytracer(W, H, device=0)
+    ref.build_bvh(scene)
+    alt = Raytracer(W, H, device=0)
+    alt.build_bvh(scene, lbvh=True)
+    for pose in POSES[:4]:
+        cam = pose_cam(pose)
+        O, D, rD = _primary_packets(np.asarray(getattr(cam, "transform", cam), np.float32), W, H)
+        t0 = np.full(O.shape[:2], 1e8, np.float32)
+        ta, ia, ua, va = ref.trace_packets(O, D, rD, t0)
+        tb, ib, ub, vb = alt.trace_packets(O, D, rD, t0)
+        assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32)), "nearest distances differ on %d rays" % int((ta != tb).sum())
+        assert np.array_equal(ia >= 0, ib >= 0)
+        differ = ia != ib
+        assert differ.mean() <= 0.001            # only exact ties may name another triangle
+        # single rays through BVH::Traverse semantics (root gate and true divisions): same distances too
+        n = O.shape[0] * 64
+        ta1, ia1, _, _ = ref.trace_rays(O.reshape(n, 3), D.reshape(n, 3), np.full(n, 1e8, np.float32))
+        tb1, ib1, _, _ = alt.trace_rays(O.reshape(n, 3), D.reshape(n, 3), np.full(n, 1e8, np.float32))
+        assert np.array_equal(ta1.view(np.uint32), tb1.view(np.uint32)) and (ia1 != ib1).mean() <= 0.001
+        # whole frames, both shaders: pixels equal wherever the triangles agree
+        for mode in (MODE_PACKET, MODE_RECURSIVE):
+            fa, ida = ref.render(cam, mode=mode)
+            fb, idb = alt.render(cam, mode=mode)
+            same = ida == idb
+            assert same.mean() >= 0.999
+            if mode == MODE_PACKET:
+                assert np.array_equal(fa[same], fb[same])
+    ref.close(); alt.close()
+
+
+def test_lbvh_tiny_scenes():
+    """1 to 9 triangles: the radix tree degenerates (single leaf, root leaf, equal Morton codes)."""
+    for n in (1, 2, 3, 4, 5, 9):
+        scene = scene_io.soup_scene(n)
+        if n == 9:      # nine copies of one triangle: all Morton codes equal
+            m = scene["meshes"][0]
+            m["pos"] = np.tile(np.asarray(m["pos"], np.float32).reshape(-1, 3)[:3], (9, 1))
+        ref = Raytracer(64, 64, device=0); ref.build_bvh(scene)
+        alt = Raytracer(64, 64, device=0); alt.build_bvh(scene, lbvh=True)
+        fa, ia = ref.render(oracle_lib.IDENTITY, mode=MODE_PACKET)
+        fb, ib = alt.render(oracle_lib.IDENTITY, mode=MODE_PACKET)
+        assert np.array_equal(ia >= 0, ib >= 0)
+        if n != 9:
+            assert np.array_equal(ia, ib) and np.array_equal(fa, fb)
+        ref.close(); alt.close()
