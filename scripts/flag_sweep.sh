@@ -8,16 +8,14 @@ CS=raytracing_amd/csrc
 OUT=raytracing_amd/variants
 BASE="-std=c++17 -O3 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -w"
 declare -A V
-V[x1]="-DMRT_XCD_RUN=1"
-V[x4]="-DMRT_XCD_RUN=4"
-V[x16]="-DMRT_XCD_RUN=16"
-V[x64]="-DMRT_XCD_RUN=64"
+V[fwd]=""
+V[rev]="-DMRT_REVERSE_TILES"
 if [ "${1:-}" = build ]; then
   mkdir -p $OUT
   make -C $CS -j8 >/dev/null
   for n in "${!V[@]}"; do
     ( /opt/rocm/bin/hipcc $BASE ${V[$n]} -c $CS/kernels.hip -o $OUT/kernels_$n.o 2>$OUT/$n.log &&
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/libmrt_$n.so $OUT/kernels_$n.o $CS/build/raster.o $CS/build/mrt_api.o $CS/build/bvh_builder.o $CS/build/camera.o &&
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/libmrt_$n.so $OUT/kernels_$n.o $CS/build/raster.o $CS/build/lbvh.o $CS/build/mrt_api.o $CS/build/bvh_builder.o $CS/build/camera.o &&
       echo "built $n" || echo "FAILED $n: $(tail -2 $OUT/$n.log)" ) &
   done
   wait
