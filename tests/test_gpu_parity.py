@@ -180,6 +180,35 @@ def test_soup_scenes_both_modes(n, lights):
     rt.close()
 
 
+@pytest.mark.parametrize("scale", [1e5, 3e-4, 1e9, 1e-9])
+def test_scaled_scenes_exact_division_paths(scale):
+    """The same soup blown up or shrunk, camera and lights with it.  Scales 1e5 and 3e-4 keep every
+    coordinate inside the ranges where the single-ray traversal replaces divisions by corrected
+    multiplications (and shadow rays decide boxes from interval bounds); 1e9 and 1e-9 leave them, so the
+    true-division code runs.  Results must equal the oracle's either way."""
+    scene = _soup_with_materials(4000, seed=11)
+    s = np.float32(scale)
+    for m in scene["meshes"]:
+        m["pos"] = (np.asarray(m["pos"], np.float32) * s).astype(np.float32)
+        if "bounds" in m:
+            m["bounds"] = (np.asarray(m["bounds"], np.float32) * s).astype(np.float32)
+    ora = oracle_lib.Oracle()
+    ora.add_scene(scene)
+    ora.build_bvh()
+    ora.set_threads(8)
+    rt = Raytracer(192, 128, device=0)
+    rt.build_bvh(scene)
+    L = np.float32([[0, 5, 0, 1, 1, 1, 1], [10, 3, -20, 0, 0.5, 0.25, 1.0]])
+    L[:, :3] *= s
+    ora.set_lights(L)
+    rt.set_lights(L)
+    for pos, target in (((0, 0, 0), (0, 0, -1)), ((5, 1, 4), (0, 0, -20))):
+        cam = oracle_lib.lookat(tuple(np.float32(pos) * s), tuple(np.float32(target) * s))
+        _check_frame(rt, ora, cam, 192, 128, MODE_PACKET)
+        _check_frame(rt, ora, cam, 192, 128, MODE_RECURSIVE, exact_pixels=False)
+    rt.close()
+
+
 def test_tiny_and_empty_scenes():
     rt = Raytracer(64, 64, device=0)
     for n in (0, 1, 2, 3):
