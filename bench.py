@@ -304,9 +304,9 @@ def main():
             head.rt.render(cam, mode=MODE_RECURSIVE, want_ids=False, fb=hf.array)
         out["host_framebuffer"] = {"ms_per_frame": round((time.perf_counter() - t0) / 10 * 1e3, 4),
                                    "ms_per_frame_pageable": round(pageable_ms, 4),
-                                   "what": "the same frame through the synchronous mrt_render (never `value`): kernel + device-to-host "
-                                           "copy over PCIe straight into a page-locked caller buffer (mrt_host_alloc); `pageable`: any "
-                                           "other caller buffer, via page-locked staging and one more memcpy"}
+                                   "what": "the same frame through the synchronous mrt_render (never `value`): the kernel writes the pixels "
+                                           "over PCIe into a page-locked caller buffer (mrt_host_alloc) while it renders; `pageable`: any "
+                                           "other caller buffer, via a device frame, page-locked staging and one more memcpy"}
         assert np.array_equal(hf.array, fbh)
         hf.close()
     if not args.no_extra:
