@@ -233,10 +233,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ray path has no CPU fallback")
+    # MRT_BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend (it moves CUDA tensors through the host) --
+    # a way to run the multi-rank code path on a one-GPU machine and check the gathered frames; timings mean nothing
+    rehearsal = os.environ.get("MRT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
@@ -258,6 +266,16 @@ def main():
                    "primary": res["primary"], "shadow": res["shadow"], "secondary": res["secondary"], "resolution": [W, H]},
     }
 
+    if rehearsal and world > 1:
+        head._finish_pending()
+        torch.cuda.synchronize()
+        if rank == 0:
+            solo = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+            head.rt.render_device(cam, solo.data_ptr(), W, mode=MODE_RECURSIVE, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            ok = all(bool(torch.equal(head.frames[r], solo)) for r in range(world))
+            print("rehearsal: %d gathered 1080p frames %s" % (world, "identical to a local render" if ok else "DIFFER"), file=sys.stderr)
+            assert ok
     ora = None
     if rank == 0:
         threads = min(16, os.cpu_count() or 1)
@@ -312,6 +330,16 @@ def main():
     if not args.no_extra:
         c4 = Workload("c4", scene, 7680, 4320, MODE_PACKET, 4, cam, rank, world, torch, dist, split="rows")
         r4 = c4.run(max(2, min(args.steps, 5)), 1)
+        if rehearsal and world > 1:
+            got = c4.frame() if rank == 0 else None
+            if rank == 0:
+                solo = torch.zeros((4320, 7680), dtype=torch.int32, device="cuda")
+                c4.rt.render_device(cam, solo.data_ptr(), 7680, mode=MODE_PACKET, spp_grid=4, stream=torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                ok = np.array_equal(got, solo.cpu().numpy().view(np.uint32))
+                print("rehearsal: 8K frame assembled from %d interleaved shares %s" % (world, "identical to a local render" if ok else "DIFFERS"),
+                      file=sys.stderr)
+                assert ok
         if rank == 0:
             out["c4_8k_16spp"] = {"workload": "same scene, ONE 7680x4320 frame per step, 4x4 sample grid (30720x17280 traced), packet path; "
                                               "tile rows dealt round-robin to the ranks, shares gathered on rank 0",
