@@ -1,5 +1,7 @@
 #include "bvh_builder.h"
 
+#include "host_parallel.h"
+
 #include <stdlib.h>
 
 #include <algorithm>
@@ -28,27 +30,29 @@ bool flatten_meshes(const mrt_mesh* meshes, int n_meshes, int n_textures, bool n
         total += (size_t)M.tris;
     }
     if (total > 0x3fffffffu) { err = "too many triangles"; return false; }
-    out.reserve(total);
+    out.resize(total);
+    size_t base = 0;
     for (int m = 0; m < n_meshes; ++m) {
         const mrt_mesh& M = meshes[m];
         const f3* pos = reinterpret_cast<const f3*>(M.pos);
         const f2* uv = reinterpret_cast<const f2*>(M.uv);
         const f3* N = reinterpret_cast<const f3*>(M.tri_normal);
-        for (int j = 0; j < M.tris; ++j) {
-            const int32_t a = M.tri[j * 3], b = M.tri[j * 3 + 1], c = M.tri[j * 3 + 2];
-            if (a < 0 || b < 0 || c < 0 || a >= M.verts || b >= M.verts || c >= M.verts) {
-                err = "triangle vertex index out of range";
-                return false;
+        std::atomic<bool> bad{false};
+        parallel_for((size_t)M.tris, [&](size_t jb, size_t je) {
+            for (size_t j = jb; j < je; ++j) {
+                const int32_t a = M.tri[j * 3], b = M.tri[j * 3 + 1], c = M.tri[j * 3 + 2];
+                if (a < 0 || b < 0 || c < 0 || a >= M.verts || b >= M.verts || c >= M.verts) { bad = true; return; }
+                HostTri& t = out[base + j];
+                t.normal = N[j];
+                t.p0 = pos[a]; t.p1 = pos[b]; t.p2 = pos[c];
+                t.centroid = ((t.p0 + t.p1) + t.p2) / 3.0f;        // raytracer.h:164
+                t.uv0 = uv[a]; t.uv1 = uv[b]; t.uv2 = uv[c];
+                t.refl = M.refl; t.refr = M.refr; t.rindex = M.rindex;
+                t.tex = M.texture_id;
             }
-            HostTri t;
-            t.normal = N[j];
-            t.p0 = pos[a]; t.p1 = pos[b]; t.p2 = pos[c];
-            t.centroid = ((t.p0 + t.p1) + t.p2) / 3.0f;        // raytracer.h:164
-            t.uv0 = uv[a]; t.uv1 = uv[b]; t.uv2 = uv[c];
-            t.refl = M.refl; t.refr = M.refr; t.rindex = M.rindex;
-            t.tex = M.texture_id;
-            out.push_back(t);
-        }
+        });
+        if (bad) { err = "triangle vertex index out of range"; out.clear(); return false; }
+        base += (size_t)M.tris;
     }
     return true;
 }

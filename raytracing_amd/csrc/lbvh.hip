@@ -21,7 +21,10 @@
 #include <string>
 #include <vector>
 
+#include <mutex>
+
 #include "bvh_builder.h"
+#include "host_parallel.h"
 
 namespace mrt {
 
@@ -191,13 +194,19 @@ bool build_lbvh_device(HostBVH& B, hipStream_t stream, std::string& err) {
     const size_t slots = (size_t)B.n_nodes_alloc + 2;
     std::vector<Tri9> host(n);
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (uint32_t i = 0; i < n; ++i) {
-        const HostTri& t = B.tris[i];
-        const float v[9] = {t.p0.x, t.p0.y, t.p0.z, t.p1.x, t.p1.y, t.p1.z, t.p2.x, t.p2.y, t.p2.z};
-        for (int k = 0; k < 9; ++k) host[i].v[k] = v[k];
-        const float c[3] = {t.centroid.x, t.centroid.y, t.centroid.z};
-        for (int a = 0; a < 3; ++a) { if (c[a] < lo[a]) lo[a] = c[a]; if (c[a] > hi[a]) hi[a] = c[a]; }
-    }
+    std::mutex mu;
+    parallel_for(n, [&](size_t b, size_t e) {
+        float l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = b; i < e; ++i) {
+            const HostTri& t = B.tris[i];
+            const float v[9] = {t.p0.x, t.p0.y, t.p0.z, t.p1.x, t.p1.y, t.p1.z, t.p2.x, t.p2.y, t.p2.z};
+            for (int k = 0; k < 9; ++k) host[i].v[k] = v[k];
+            const float c[3] = {t.centroid.x, t.centroid.y, t.centroid.z};
+            for (int a = 0; a < 3; ++a) { if (c[a] < l[a]) l[a] = c[a]; if (c[a] > h[a]) h[a] = c[a]; }
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        for (int a = 0; a < 3; ++a) { if (l[a] < lo[a]) lo[a] = l[a]; if (h[a] > hi[a]) hi[a] = h[a]; }
+    });
     float inv[3];
     for (int a = 0; a < 3; ++a) {
         if (!(lo[a] <= hi[a])) { lo[a] = 0; hi[a] = 0; }            // all-NaN axis
@@ -255,13 +264,15 @@ bool build_lbvh_device(HostBVH& B, hipStream_t stream, std::string& err) {
         B.max_depth = 0;
         return true;
     }
-    for (size_t i = 0; i < slots; ++i) {
-        const float4 a = h_nodes[2 * i], b = h_nodes[2 * i + 1];
-        B.nmin[i] = {a.x, a.y, a.z};
-        B.nmax[i] = {b.x, b.y, b.z};
-        memcpy(&B.first[i], &a.w, 4);
-        memcpy(&B.count[i], &b.w, 4);
-    }
+    parallel_for(slots, [&](size_t sb, size_t se) {
+        for (size_t i = sb; i < se; ++i) {
+            const float4 a = h_nodes[2 * i], b = h_nodes[2 * i + 1];
+            B.nmin[i] = {a.x, a.y, a.z};
+            B.nmax[i] = {b.x, b.y, b.z};
+            memcpy(&B.first[i], &a.w, 4);
+            memcpy(&B.count[i], &b.w, 4);
+        }
+    });
     B.pool_ptr = (uint32_t)slots - 1;          // highest slot in use
     B.max_depth = h_depth;
     return true;

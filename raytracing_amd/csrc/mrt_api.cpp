@@ -6,12 +6,15 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/mrt.h"
 #include "bvh_builder.h"
+#include "host_parallel.h"
 #include "device_scene.h"
 #include "mrt_math.h"
 #include "raster.h"
@@ -276,12 +279,22 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     MRT_HIP(c, hipSetDevice(c->device));
     std::string err;
     c->has_scene = false;
+    const bool timing = getenv("MRT_TIMING") != nullptr;           // tuning aid: stage times of the upload on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    auto stage = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "mrt_scene_upload: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     if (!flatten_meshes(meshes, n_meshes, n_textures, true, c->bvh.tris, err)) return fail(c, MRT_E_ARG, err);
+    stage("flatten");
     if (lbvh && !c->bvh.tris.empty()) {
         if (!build_lbvh_device(c->bvh, c->stream, err)) return fail(c, MRT_E_HIP, err);
     } else {
         build_bvh(c->bvh);
     }
+    stage(lbvh ? "tree (GPU)" : "tree (host)");
     const HostBVH& B = c->bvh;
     if (B.max_depth + 2 > kStackDepth) return fail(c, MRT_E_LIMIT, "BVH deeper than the traversal stack (62 levels)");
     if (B.pool_ptr >= (1u << 26)) return fail(c, MRT_E_LIMIT, "too many BVH nodes for the packet work list encoding");
@@ -290,34 +303,39 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     // nodes: slots 0..pool_ptr (1 and 2 unused); leaves point into the leaf-ordered records
     const size_t slots = (size_t)B.pool_ptr + 1;
     std::vector<float4> nodes(2 * slots);
-    for (size_t i = 0; i < slots; ++i) {
-        nodes[2 * i] = make_float4(B.nmin[i].x, B.nmin[i].y, B.nmin[i].z, bits2f(B.first[i]));
-        nodes[2 * i + 1] = make_float4(B.nmax[i].x, B.nmax[i].y, B.nmax[i].z, bits2f(B.count[i]));
-    }
     // exact-division shortcut of the single-ray traversal: every bound must be 0 or of ordinary size
-    bool coords_ok = true;
-    for (size_t i = 0; i < slots && coords_ok; ++i) {
-        if (i == 1 || i == 2) continue;
-        const float c6[6] = {B.nmin[i].x, B.nmin[i].y, B.nmin[i].z, B.nmax[i].x, B.nmax[i].y, B.nmax[i].z};
-        for (float v : c6) coords_ok = coords_ok && div_shortcut_coord_ok(v);
-    }
+    std::atomic<bool> coords_all_ok{true};
+    parallel_for(slots, [&](size_t b, size_t e) {
+        bool ok = true;
+        for (size_t i = b; i < e; ++i) {
+            nodes[2 * i] = make_float4(B.nmin[i].x, B.nmin[i].y, B.nmin[i].z, bits2f(B.first[i]));
+            nodes[2 * i + 1] = make_float4(B.nmax[i].x, B.nmax[i].y, B.nmax[i].z, bits2f(B.count[i]));
+            if (i == 1 || i == 2) continue;
+            const float c6[6] = {B.nmin[i].x, B.nmin[i].y, B.nmin[i].z, B.nmax[i].x, B.nmax[i].y, B.nmax[i].z};
+            for (float v : c6) ok = ok && div_shortcut_coord_ok(v);
+        }
+        if (!ok) coords_all_ok = false;
+    });
+    const bool coords_ok = coords_all_ok;
     std::vector<float4> triA(B.n_tris), triB(B.n_tris), attr(4 * (size_t)B.n_tris);
     std::vector<float2> triC(B.n_tris);
-    for (uint32_t k = 0; k < B.n_tris; ++k) {
-        const uint32_t id = B.idx[k];
-        const HostTri& t = B.tris[id];
-        const f3 e1 = t.p1 - t.p0, e2 = t.p2 - t.p0;      // raytracer.cpp:289-290
-        triA[k] = make_float4(t.p0.x, t.p0.y, t.p0.z, e1.x);
-        triB[k] = make_float4(e1.y, e1.z, e2.x, e2.y);
-        triC[k] = make_float2(e2.z, bits2f(id));
-    }
-    for (uint32_t id = 0; id < B.n_tris; ++id) {
-        const HostTri& t = B.tris[id];
-        attr[4 * (size_t)id] = make_float4(t.normal.x, t.normal.y, t.normal.z, t.refl);
-        attr[4 * (size_t)id + 1] = make_float4(t.uv0.x, t.uv0.y, t.uv1.x, t.uv1.y);
-        attr[4 * (size_t)id + 2] = make_float4(t.uv2.x, t.uv2.y, t.refr, t.rindex);
-        attr[4 * (size_t)id + 3] = make_float4(bits2f((uint32_t)t.tex), 0, 0, 0);
-    }
+    parallel_for(B.n_tris, [&](size_t b, size_t e) {
+        for (size_t k = b; k < e; ++k) {
+            const uint32_t id = B.idx[k];
+            const HostTri& t = B.tris[id];
+            const f3 e1 = t.p1 - t.p0, e2 = t.p2 - t.p0;      // raytracer.cpp:289-290
+            triA[k] = make_float4(t.p0.x, t.p0.y, t.p0.z, e1.x);
+            triB[k] = make_float4(e1.y, e1.z, e2.x, e2.y);
+            triC[k] = make_float2(e2.z, bits2f(id));
+        }
+        for (size_t id = b; id < e; ++id) {
+            const HostTri& t = B.tris[id];
+            attr[4 * id] = make_float4(t.normal.x, t.normal.y, t.normal.z, t.refl);
+            attr[4 * id + 1] = make_float4(t.uv0.x, t.uv0.y, t.uv1.x, t.uv1.y);
+            attr[4 * id + 2] = make_float4(t.uv2.x, t.uv2.y, t.refr, t.rindex);
+            attr[4 * id + 3] = make_float4(bits2f((uint32_t)t.tex), 0, 0, 0);
+        }
+    });
     std::vector<int4> tex(n_textures);
     std::vector<uint8_t> texels;
     std::vector<uint32_t> pal((size_t)n_textures * 32 * 256);
@@ -328,6 +346,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
         memcpy(pal.data() + (size_t)i * 32 * 256, textures[i].palettes, 32 * 256 * 4);
         if (texels.size() > 0x7fffffffu) return fail(c, MRT_E_LIMIT, "textures exceed 2 GiB of texels");
     }
+    stage("pack arrays");
     MRT_HIP(c, c->d_nodes.upload(nodes, c->stream));
     MRT_HIP(c, c->d_triA.upload(triA, c->stream));
     MRT_HIP(c, c->d_triB.upload(triB, c->stream));
@@ -337,8 +356,10 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     MRT_HIP(c, c->d_texels.upload(texels, c->stream));
     MRT_HIP(c, c->d_pal.upload(pal, c->stream));
     MRT_HIP(c, c->d_lights.upload(c->lights, c->stream));
+    stage("upload ray-path arrays");
     if (int rc = raster_upload(c->raster, meshes, n_meshes, c->stream, err)) return fail(c, rc, err);
     MRT_HIP(c, hipStreamSynchronize(c->stream));
+    stage("rasterizer arrays");
     refresh_scene_view(c);
     c->scene.n_textures = n_textures;
     c->scene.n_node_slots = (int)slots;
