@@ -471,3 +471,14 @@ def test_cpp_host_driver_renders_reference_frame(tmp_path, known):
     rt.close()
     assert "%016x" % oracle_lib.fbhash(fb) == known["packet_frames"][1]["fbhash"]
     assert np.array_equal((rgb[..., 0] << 16) | (rgb[..., 1] << 8) | rgb[..., 2], fb & 0xFFFFFF)
+
+
+def test_random_pose_campaign():
+    """scripts/parity_fuzz.py: 80 random cameras (some on integer coordinates, some looking straight down), random
+    light positions, four frame sizes, every fifth pose with a 2x2 sample grid, both shaders."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    import os
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "parity_fuzz.py"), "80", "3"], capture_output=True, text=True)
+    assert r.returncode == 0 and "hit ids identical" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
