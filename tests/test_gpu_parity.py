@@ -482,3 +482,6 @@ def test_random_pose_campaign():
     import os
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "parity_fuzz.py"), "80", "3"], capture_output=True, text=True)
     assert r.returncode == 0 and "hit ids identical" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
+    # and 25 random triangle soups with random reflecting / refracting materials and 0-3 lights
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "parity_fuzz.py"), "--soups", "25", "9"], capture_output=True, text=True)
+    assert r.returncode == 0 and "hit ids identical" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
