@@ -118,9 +118,15 @@ __device__ __forceinline__ void slab_terms(f3 tMin, f3 tMax, float& tNear, float
 }
 // Same terms when no operand can be a NaN: hardware min/max then agree with compare+select
 // except for the sign of a zero, which none of the predicates below can see.
+// The instructions are named directly: fminf / fmaxf make the compiler quiet possible signalling
+// NaNs first (one extra v_max x,x per operand), which cannot occur here.
+__device__ __forceinline__ float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float hw_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float hw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ void slab_terms_finite(f3 tMin, f3 tMax, float& tNear, float& tFar) {
-    tNear = fmaxf(fmaxf(fminf(tMin.x, tMax.x), fminf(tMin.y, tMax.y)), fminf(tMin.z, tMax.z));
-    tFar = fminf(fminf(fmaxf(tMin.x, tMax.x), fmaxf(tMin.y, tMax.y)), fmaxf(tMin.z, tMax.z));
+    tNear = hw_max3(hw_min(tMin.x, tMax.x), hw_min(tMin.y, tMax.y), hw_min(tMin.z, tMax.z));
+    tFar = hw_min3(hw_max(tMin.x, tMax.x), hw_max(tMin.y, tMax.y), hw_max(tMin.z, tMax.z));
 }
 __device__ __forceinline__ bool slab_pass(float tNear, float tFar, float t) {
     return (tFar >= tNear) && (tNear < t) && (tFar > 0);
