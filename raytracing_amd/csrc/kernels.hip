@@ -282,16 +282,10 @@ struct LaneStack3 {
 // child at once from the terms already computed.  Visiting a leaf tests every lane >= i
 // against every triangle of the leaf, in leaf order.
 // ---------------------------------------------------------------------------------------
-template <class SC>
-__device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, f3 D, f3 rD, float& t, Hit& h, int lane, Watch& wd) {
-    if (n_tris == 0) return;
-    // With every 1/D component finite, (bound - O) * rD is never a NaN, and hardware min/max
-    // then give the predicates the same values as glm's compare+select (up to the sign of a
-    // zero, which no comparison sees).  A wave holding an axis-parallel ray (1/0 = inf) takes
-    // the compare+select form.
-    const bool finite = !__any(!(fabsf(rD.x) < INFINITY && fabsf(rD.y) < INFINITY && fabsf(rD.z) < INFINITY));
+template <bool FINITE, class SC>
+__device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f3 rD, float& t, Hit& h, int lane, Watch& wd) {
     auto terms = [&](f3 bmin, f3 bmax, float& tn, float& tf) {
-        if (finite) slab_terms_finite((bmin - O) * rD, (bmax - O) * rD, tn, tf);
+        if (FINITE) slab_terms_finite((bmin - O) * rD, (bmax - O) * rD, tn, tf);
         else slab_terms((bmin - O) * rD, (bmax - O) * rD, tn, tf);
     };
     LaneStack1 work;
@@ -350,6 +344,18 @@ __device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, 
             count = right_first ? wbits(r1) : wbits(l1);
         }
     }
+}
+
+template <class SC>
+__device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, f3 D, f3 rD, float& t, Hit& h, int lane, Watch& wd) {
+    if (n_tris == 0) return;
+    // With every 1/D component finite, (bound - O) * rD is never a NaN, and hardware min/max
+    // then give the predicates the same values as glm's compare+select (up to the sign of a
+    // zero, which no comparison sees).  A wave holding an axis-parallel ray (1/0 = inf) runs the
+    // compare+select instance of the traversal.
+    const bool finite = !__any(!(fabsf(rD.x) < INFINITY && fabsf(rD.y) < INFINITY && fabsf(rD.z) < INFINITY));
+    if (finite) traverse_packet_impl<true>(sc, O, D, rD, t, h, lane, wd);
+    else traverse_packet_impl<false>(sc, O, D, rD, t, h, lane, wd);
 }
 
 // ---------------------------------------------------------------------------------------
