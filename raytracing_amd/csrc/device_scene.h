@@ -71,6 +71,11 @@ struct FrameDev {
     // adds into group (tile % kStatSlots) so that the atomics of concurrent waves spread over
     // many lines instead of queueing on one address; the host sums the groups.
     unsigned long long* counters;
+    // Temporal load balancing of the persistent kernel (both optional).  tile_cost[tile]: shader
+    // clocks this launch spent on the tile.  tile_order: a permutation of [0, n_tiles), most
+    // expensive tiles of the previous launch first; the queues hand tiles out in that order.
+    uint32_t* tile_cost;
+    const uint32_t* tile_order;
 };
 
 constexpr int kStatSlots = 256;

@@ -842,11 +842,49 @@ __global__ __launch_bounds__(kResidentThreads) void render_tiles_resident(SceneD
         unsigned long long next = 0;
         if (lane == 0) next = atomicAdd(&F.counters[kQueueBase + 16 * q], 1ull);
         const int idx = __builtin_amdgcn_readfirstlane((int)next);
-        const int tile = idx * n_queues + q;
-        if (tile >= F.n_tiles) { q = (q + 1 == n_queues) ? 0 : q + 1; ++dry; continue; }
+        const int pos = idx * n_queues + q;
+        if (pos >= F.n_tiles) { q = (q + 1 == n_queues) ? 0 : q + 1; ++dry; continue; }
         dry = 0;
+        const int tile = F.tile_order ? (int)F.tile_order[pos] : pos;
+        const unsigned long long t0 = __builtin_readcyclecounter();
         render_tile<MODE>(sc, S, F, tile, lane, stack);
+        if (F.tile_cost && lane == 0) {
+            const unsigned long long dt = __builtin_readcyclecounter() - t0;
+            F.tile_cost[tile] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
+        }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// order[] = the tiles sorted by decreasing cost of the previous launch, to 1/8 octave (a counting
+// sort over 256 keys by one workgroup; the order inside a key is arbitrary).  A frame ends when its
+// last tile ends, and a tile of the recursive shader can take tens of times the average: started
+// last it leaves the rest of the chip idle, started first it overlaps with everything else.
+// Any permutation renders the same frame; the costs only steer the order.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t cost_key(uint32_t cost) {
+    const uint32_t b = __float_as_uint((float)cost) >> 20;            // exponent and 3 significand bits
+    const uint32_t k = b > (127u << 3) ? b - (127u << 3) : 0u;         // cost 1 -> 0, cost 2^32 -> 256
+    return 255u - (k > 255u ? 255u : k);                                // expensive first
+}
+__global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t* cost, uint32_t* order, int n) {
+    __shared__ uint32_t bin[256];
+    __shared__ uint32_t scan[256];
+    const int t = threadIdx.x;
+    if (t < 256) bin[t] = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) atomicAdd(&bin[cost_key(cost[i])], 1u);
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (int k = 0; k < 256; ++k) { scan[k] = run; run += bin[k]; }
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) order[atomicAdd(&scan[cost_key(cost[i])], 1u)] = (uint32_t)i;
+}
+hipError_t launch_order_tiles(const uint32_t* cost, uint32_t* order, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--pose", default="P0")
     ap.add_argument("--only", default="", help="packet|recursive")
     ap.add_argument("--lights", default="", help="0|1: only this light count")
+    ap.add_argument("--walk", type=float, default=0.0,
+                    help="move the camera this many units sideways every frame (the frame loop walks 10 units/s, game.cpp:57-62)")
     ap.add_argument("--opaque", action="store_true", help="set refl = refr = 0 on every mesh (primary and shadow rays only)")
     args = ap.parse_args()
     import torch
@@ -48,7 +50,11 @@ def main():
                 rt.render_device(cam, fb.data_ptr(), args.w, mode=mode, stream=stream.cuda_stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
-            for _ in range(args.iters):
+            for i in range(args.iters):
+                if args.walk:
+                    x, y, z = cam.get_position()
+                    step = args.walk if (i // 25) % 2 == 0 else -args.walk      # there and back
+                    cam.set_position((x + step, y, z))
                 rt.render_device(cam, fb.data_ptr(), args.w, mode=mode, stream=stream.cuda_stream)
             e1.record(stream)
             torch.cuda.synchronize()

@@ -437,6 +437,28 @@ def test_launches_on_two_streams_do_not_disturb_each_other(maze_scene):
     rt.close()
 
 
+@pytest.mark.parametrize("W,H", [(1000, 600), (16, 8), (256, 8)])
+def test_tile_order_from_previous_frame_changes_nothing(maze_scene, monkeypatch, W, H):
+    """The persistent kernel starts the tiles that were expensive in the previous launch of the same
+    shape first.  Pixels, hit IDs and ray counters must not depend on that order: frames of a
+    context that has a history (same pose again, then another pose) equal the frames rendered with
+    the ordering switched off."""
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(maze_scene)
+    cams = [pose_cam(POSES[0]), pose_cam(POSES[2])]
+    monkeypatch.setenv("MRT_NO_TILE_ORDER", "1")
+    base = []
+    for cam in cams:
+        fb, ids = rt.render(cam, mode=MODE_RECURSIVE)
+        base.append((fb.copy(), ids.copy(), rt.ray_counts()))
+    monkeypatch.delenv("MRT_NO_TILE_ORDER")
+    for which in (0, 0, 0, 1, 1, 0):
+        fb, ids = rt.render(cams[which], mode=MODE_RECURSIVE)
+        assert np.array_equal(ids, base[which][1]) and np.array_equal(fb, base[which][0])
+        assert rt.ray_counts() == base[which][2]
+    rt.close()
+
+
 def test_error_paths(maze_scene):
     rt = Raytracer(64, 64, device=0)
     with pytest.raises(MrtError, match="scene_upload"):
