@@ -26,6 +26,8 @@ Rank 0 prints one JSON line.  Besides the contract's keys it carries
                    ONE frame per step split over the ranks, measured at every N so its strong
                    scaling can be read from the same files;
   c1_512_packet -- the reference's own 512x512 configuration, GPU and CPU;
+  walking_camera -- the headline workload with a moving camera (the persistent kernel orders its tiles by the
+                    previous frame's costs; a camera at rest is the best case of that);
   c3_1m_tris_4k -- synthetic 1,000,000-triangle soup at 3840x2160, packet path (scene in global
                    memory, divergent traversal);
   c5_raster_1m_4k -- the rasterizer path on the same soup (rank 0 only; host framebuffer copy
@@ -327,6 +329,27 @@ def main():
                                            "other caller buffer, via a device frame, page-locked staging and one more memcpy"}
         assert np.array_equal(hf.array, fbh)
         hf.close()
+        # The persistent kernel starts the tiles first that were expensive in the previous frame, so a camera at
+        # rest is its best case.  The same workload with the camera walking sideways at the frame loop's speed
+        # (10 units/s, game.cpp:57-62) at 60 frames/s, 25 frames there and 25 back:
+        def walk(n_frames, count_rays):
+            c, rays = cam.copy(), 0
+            for i in range(n_frames):
+                c[12] += 0.16 if (i // 25) % 2 == 0 else -0.16
+                head.rt.render_device(c, head.fb[0].data_ptr(), W, mode=MODE_RECURSIVE, stream=torch.cuda.current_stream().cuda_stream)
+                if count_rays:
+                    k = head.rt.ray_counts()
+                    rays += k["primary"] + k["shadow"] + k["secondary"]
+            return rays
+        walk_rays = walk(100, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        walk(100, False)
+        torch.cuda.synchronize()
+        walk_s = time.perf_counter() - t0
+        out["walking_camera"] = {"ms_per_frame": round(walk_s / 100 * 1e3, 4), "value": round(walk_rays / walk_s / 1e6, 3), "unit": "Mrays/s",
+                                 "what": "the headline workload with the camera moving 0.16 units per frame (never `value`): the tile "
+                                         "order of each frame comes from the costs measured in the previous, different frame"}
     if not args.no_extra:
         c4 = Workload("c4", scene, 7680, 4320, MODE_PACKET, 4, cam, rank, world, torch, dist, split="rows")
         r4 = c4.run(max(2, min(args.steps, 5)), 1)
