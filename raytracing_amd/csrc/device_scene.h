@@ -82,13 +82,16 @@ constexpr int kStatSlots = 256;
 constexpr int kTileQueues = 32;
 constexpr int kQueueBase = 16;
 constexpr int kStatBase = kQueueBase + 16 * kTileQueues;
+// 256 32-bit words after the statistics: histogram of the tile-ordering sort.  Zeroed with the rest
+// at the start of every frame; the ordering kernels run between that and the frame kernel.
+constexpr int kOrderHistBase = kStatBase + 16 * kStatSlots;
 #ifdef MRT_LOOP_COUNTS
 // Diagnostic build only (make prof): per-site loop iteration counts, wave level and lane level.
 constexpr int kProfSites = 16;
-constexpr int kProfBase = kStatBase + 16 * kStatSlots;
+constexpr int kProfBase = kOrderHistBase + 128;
 constexpr int kCounterSlots = kProfBase + 2 * kProfSites;
 #else
-constexpr int kCounterSlots = kStatBase + 16 * kStatSlots;
+constexpr int kCounterSlots = kOrderHistBase + 128;
 #endif
 constexpr int kStackDepth = 64;        // per-ray traversal stack entries; BVH depth must stay below
 constexpr int kResidentThreads = 1024; // workgroup size of the LDS-resident kernel (16 waves)

@@ -856,34 +856,56 @@ __global__ __launch_bounds__(kResidentThreads) void render_tiles_resident(SceneD
 }
 
 // ---------------------------------------------------------------------------------------
-// order[] = the tiles sorted by decreasing cost of the previous launch, to 1/8 octave (a counting
-// sort over 256 keys by one workgroup; the order inside a key is arbitrary).  A frame ends when its
-// last tile ends, and a tile of the recursive shader can take tens of times the average: started
-// last it leaves the rest of the chip idle, started first it overlaps with everything else.
-// Any permutation renders the same frame; the costs only steer the order.
+// order[] = the tiles sorted by decreasing cost of the previous launch, to 1/8 octave: a counting
+// sort over 256 keys in two small kernels (the order inside a key is arbitrary).  A frame ends
+// when its last tile ends, and a tile of the recursive shader can take ten times the average:
+// started last it leaves the rest of the chip idle, started first it overlaps with everything
+// else.  Any permutation renders the same frame; the costs only steer the order.
+//   tile_keys_kernel:  packed[i] = key << 24 | rank of tile i among the tiles with its key
+//                      (hist[key] must be zero on entry and holds the key's tile count afterwards)
+//   tile_order_kernel: order[first[key] + rank] = i, first = exclusive prefix sum of hist
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t cost_key(uint32_t cost) {
     const uint32_t b = __float_as_uint((float)cost) >> 20;            // exponent and 3 significand bits
     const uint32_t k = b > (127u << 3) ? b - (127u << 3) : 0u;         // cost 1 -> 0, cost 2^32 -> 256
     return 255u - (k > 255u ? 255u : k);                                // expensive first
 }
-__global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t* cost, uint32_t* order, int n) {
-    __shared__ uint32_t bin[256];
-    __shared__ uint32_t scan[256];
-    const int t = threadIdx.x;
-    if (t < 256) bin[t] = 0;
+__global__ __launch_bounds__(1024) void tile_keys_kernel(const uint32_t* cost, uint32_t* packed, uint32_t* hist, int n) {
+    __shared__ uint32_t count[256], base[256];
+    const int t = threadIdx.x, i = (int)blockIdx.x * 1024 + t;
+    if (t < 256) count[t] = 0;
     __syncthreads();
-    for (int i = t; i < n; i += 1024) atomicAdd(&bin[cost_key(cost[i])], 1u);
+    const uint32_t key = i < n ? cost_key(cost[i]) : 0u;
+    const uint32_t local = i < n ? atomicAdd(&count[key], 1u) : 0u;
     __syncthreads();
-    if (t == 0) {
-        uint32_t run = 0;
-        for (int k = 0; k < 256; ++k) { scan[k] = run; run += bin[k]; }
+    if (t < 256 && count[t]) base[t] = atomicAdd(&hist[t], count[t]);
+    __syncthreads();
+    if (i < n) packed[i] = (key << 24) | (base[key] + local);
+}
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* packed, const uint32_t* hist, uint32_t* order, int n) {
+    __shared__ uint32_t first[256];
+    const int t = threadIdx.x, i = (int)blockIdx.x * 1024 + t;
+    if (t < 64) {            // one wave: exclusive prefix sum of the 256 counts, four per lane
+        const uint32_t c0 = hist[4 * t], c1 = hist[4 * t + 1], c2 = hist[4 * t + 2], c3 = hist[4 * t + 3];
+        uint32_t incl = c0 + c1 + c2 + c3;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if (t >= o) incl += up;
+        }
+        const uint32_t excl = incl - (c0 + c1 + c2 + c3);
+        first[4 * t] = excl; first[4 * t + 1] = excl + c0; first[4 * t + 2] = excl + c0 + c1; first[4 * t + 3] = excl + c0 + c1 + c2;
     }
     __syncthreads();
-    for (int i = t; i < n; i += 1024) order[atomicAdd(&scan[cost_key(cost[i])], 1u)] = (uint32_t)i;
+    if (i < n) {
+        const uint32_t p = packed[i];
+        order[first[p >> 24] + (p & 0xffffffu)] = (uint32_t)i;
+    }
 }
-hipError_t launch_order_tiles(const uint32_t* cost, uint32_t* order, int n, hipStream_t stream) {
-    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n);
+// n < 2^24.  hist: 256 words, zero on entry.
+hipError_t launch_order_tiles(const uint32_t* cost, uint32_t* packed, uint32_t* hist, uint32_t* order, int n, hipStream_t stream) {
+    const dim3 grid((unsigned)((n + 1023) / 1024)), block(1024);
+    hipLaunchKernelGGL(tile_keys_kernel, grid, block, 0, stream, cost, packed, hist, n);
+    hipLaunchKernelGGL(tile_order_kernel, grid, block, 0, stream, packed, (const uint32_t*)hist, order, n);
     return hipGetLastError();
 }
 

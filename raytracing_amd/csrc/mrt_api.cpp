@@ -21,7 +21,7 @@
 
 namespace mrt {
 hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool resident, int n_cus, hipStream_t stream);
-hipError_t launch_order_tiles(const uint32_t* cost, uint32_t* order, int n, hipStream_t stream);
+hipError_t launch_order_tiles(const uint32_t* cost, uint32_t* packed, uint32_t* hist, uint32_t* order, int n, hipStream_t stream);
 size_t resident_lds_bytes(int n_node_slots, int n_tris, int stack_entries);
 hipError_t launch_trace_packets(const SceneDev& S, int n_packets, const float* O, const float* D, const float* rD,
                                 float* t, int32_t* tri, float* u, float* v, hipStream_t stream);
@@ -78,7 +78,7 @@ struct mrt_ctx {
     DevBuf<unsigned long long> d_counters;
     // per-tile clocks of the last persistent-kernel launch and the tile order derived from them;
     // cost_shape identifies the launch they belong to (0: none)
-    DevBuf<uint32_t> d_tile_cost, d_tile_order;
+    DevBuf<uint32_t> d_tile_cost, d_tile_packed, d_tile_order;
     unsigned long long cost_shape = 0;
     hipStream_t last_stream = nullptr;
     hipEvent_t last_done = nullptr;   // recorded after every frame launch: the context's counters and queues are shared,
@@ -186,16 +186,18 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
     // loads through the scalar cache) and runs faster with one wave per tile at 8 waves per SIMD.
     bool resident = c->resident && mode == (int)MRT_MODE_RECURSIVE;
     if (const char* e = getenv("MRT_RESIDENT_PACKET")) resident = c->resident && atoi(e) != 0;   // tuning aid
-    if (resident && !getenv("MRT_NO_TILE_ORDER")) {
+    if (resident && F.n_tiles < (1 << 24) && !getenv("MRT_NO_TILE_ORDER")) {
         // Launches of the same shape follow each other in a frame loop with a slowly moving camera:
         // start the tiles that were expensive last time first.
         const unsigned long long shape = ((unsigned long long)F.n_tiles << 24) ^ ((unsigned long long)F.tile_y0 << 12) ^
                                          ((unsigned long long)g << 8) ^ ((unsigned long long)F.part << 4) ^
                                          ((unsigned long long)F.n_parts << 16) ^ ((unsigned long long)F.part_block << 40) ^ ((unsigned long long)mode << 1) ^ 1ull;
         MRT_HIP(c, c->d_tile_cost.ensure((size_t)F.n_tiles));
+        MRT_HIP(c, c->d_tile_packed.ensure((size_t)F.n_tiles));
         MRT_HIP(c, c->d_tile_order.ensure((size_t)F.n_tiles));
         if (c->cost_shape == shape) {
-            MRT_HIP(c, launch_order_tiles(c->d_tile_cost.p, c->d_tile_order.p, F.n_tiles, stream));
+            MRT_HIP(c, launch_order_tiles(c->d_tile_cost.p, c->d_tile_packed.p, reinterpret_cast<uint32_t*>(c->d_counters.p + kOrderHistBase),
+                                          c->d_tile_order.p, F.n_tiles, stream));
             F.tile_order = c->d_tile_order.p;
         }
         F.tile_cost = c->d_tile_cost.p;
@@ -257,7 +259,7 @@ void mrt_destroy(mrt_ctx* c) {
     c->d_nodes.release(); c->d_triA.release(); c->d_triB.release(); c->d_triC.release(); c->d_attr.release(); c->d_lights.release();
     c->d_tex.release(); c->d_texels.release(); c->d_pal.release();
     c->d_fb.release(); c->d_ids.release(); c->d_counters.release();
-    c->d_tile_cost.release(); c->d_tile_order.release();
+    c->d_tile_cost.release(); c->d_tile_packed.release(); c->d_tile_order.release();
     raster_release(c->raster);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->last_done) (void)hipEventDestroy(c->last_done);
