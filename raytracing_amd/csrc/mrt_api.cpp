@@ -518,7 +518,9 @@ extern "C" int mrt_debug_loop_counts(mrt_ctx* c, uint64_t* out) {
     MRT_HIP(c, hipMemcpy(out, c->d_counters.p + kProfBase, 2 * kProfSites * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return MRT_OK;
 }
-// diagnostic build only: shader clocks per tile of the last persistent-kernel launch; returns the tile count
+#endif
+#if defined(MRT_LOOP_COUNTS) || defined(MRT_DEBUG_API)
+// diagnostic builds only: shader clocks per tile of the last persistent-kernel launch; returns the tile count
 extern "C" int mrt_debug_tile_costs(mrt_ctx* c, uint32_t* out, int capacity) {
     if (!c || !out) return MRT_E_ARG;
     MRT_HIP(c, hipSetDevice(c->device));

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-tile shader clocks of the persistent recursive kernel (diagnostic build: make -C raytracing_amd/csrc prof):
+"""Per-tile shader clocks of the persistent recursive kernel (release kernels with the diagnostic accessor: make -C raytracing_amd/csrc diag):
 distribution, and the bound a perfect schedule could reach.  A tuning aid."""
 import ctypes as C
 import os
@@ -12,8 +12,9 @@ sys.path.insert(0, ROOT)
 
 
 def main():
+    mode = int(sys.argv[1]) if len(sys.argv) > 1 else 1       # 0: packet path (needs MRT_RESIDENT_PACKET=1), 1: recursive
     from raytracing_amd import binding
-    binding.LIB_PATH = os.path.join(ROOT, "raytracing_amd", "libmrt_prof.so")
+    binding.LIB_PATH = os.path.join(ROOT, "raytracing_amd", "libmrt_diag.so")
     import torch
     from raytracing_amd import Camera, Raytracer, scene_io
     L = binding.lib()
@@ -26,7 +27,7 @@ def main():
     stream = torch.cuda.current_stream()
     cam = Camera()
     for _ in range(3):
-        rt.render_device(cam, fb.data_ptr(), w, mode=1, stream=stream.cuda_stream)
+        rt.render_device(cam, fb.data_ptr(), w, mode=mode, stream=stream.cuda_stream)
     torch.cuda.synchronize()
     n = (w // 8) * (h // 8)
     cost = np.zeros(n, np.uint32)
@@ -36,6 +37,9 @@ def main():
     print("tiles %d  sum %.3g clocks  mean %.0f  median %.0f  p90 %.0f  p99 %.0f  max %.0f" %
           (got, c.sum(), c.mean(), np.median(c), np.percentile(c, 90), np.percentile(c, 99), c.max()))
     print("perfect balance over %d waves: %.0f clocks per wave; heaviest tile: %.0f clocks" % (waves, c.sum() / waves, c.max()))
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    np.save(os.path.join(out, "tile_costs_mode%d.npy" % mode), cost[:got])
     grid = c.reshape(h // 8, w // 8)
     rows = grid.mean(axis=1)
     print("mean cost per tile row (every 9th):", " ".join("%.0f" % r for r in rows[::9]))
