@@ -63,7 +63,12 @@ class Workload:
     split = "rows": ONE frame per step; 8-row tile rows are dealt round-robin to the ranks, ranks
     other than 0 render their share packed and send it, rank 0 renders in place and scatters what
     it receives (multigpu.PartGather).
-    Frames are double-buffered so that the transfer of step i overlaps the rendering of step i+1."""
+    split = "rows" double-buffers: the transfer of step i overlaps the rendering of step i+1.
+    split = "frames" uses three buffers and waits for the transfer of step i only before step i+3
+    renders into the same buffer.  The persistent frame kernel takes every CU's whole register file,
+    so a send/recv kernel issued behind a frame cannot start before the NEXT frame boundary (measured
+    with a stand-in kernel: scripts/native/coresidency.hip); with two buffers every frame would wait
+    for a transfer that could only begin when the frame before it had ended."""
 
     def __init__(self, name, scene, width, height, mode, grid, cam, rank, world, torch, dist, split="frames", rt=None, device="cuda"):
         from raytracing_amd.multigpu import PartGather
@@ -76,15 +81,23 @@ class Workload:
             rt.build_bvh(scene)
         self.rt = rt
         self.events, self.pending, self.i = [], [], 0
+        self.inflight = {}                 # split == "frames": step index -> transfers that read that step's buffer
         if world == 1 or split == "frames":
-            self.fb = [torch.zeros((height, width), dtype=torch.int32, device=device) for _ in range(2 if world > 1 else 1)]
+            self.fb = [torch.zeros((height, width), dtype=torch.int32, device=device) for _ in range(3 if world > 1 else 1)]
             self.frames = torch.zeros((world, height, width), dtype=torch.int32, device=device) if (world > 1 and rank == 0) else None
         else:
             self.pg = PartGather(height, width, world, rank, 1, torch, device, torch.int32)
             rows = height if rank == 0 else max(8, self.pg.n_rows[rank])
             self.fb = [torch.zeros((rows, width), dtype=torch.int32, device=device) for _ in range(2)]
 
+    def _retire(self, upto):
+        """Waits for the transfers of every step <= upto (split == "frames")."""
+        for k in sorted(k for k in self.inflight if k <= upto):
+            for w in self.inflight.pop(k):
+                w.wait()
+
     def _finish_pending(self):
+        self._retire(self.i)
         for w in self.pending:
             w.wait()
         self.pending = []
@@ -110,7 +123,10 @@ class Workload:
         stream_h = stream.cuda_stream if self.gpu else None
         timed = timed and self.gpu
         fb = self.fb[self.i % len(self.fb)]
+        step_no = self.i
         self.i += 1
+        if self.world > 1 and self.split == "frames":
+            self._retire(step_no - len(self.fb))      # the transfer that read this buffer last
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
@@ -120,19 +136,20 @@ class Workload:
             self.events.append((e0, e1))
         if self.world == 1:
             return
-        self._finish_pending()             # the previous step's transfer ran under this step's kernel
         if self.split == "frames":
             if self.rank == 0:
                 self.frames[0].copy_(fb)
                 ops = [dist.P2POp(dist.irecv, self.frames[r], r) for r in range(1, self.world)]
             else:
                 ops = [dist.P2POp(dist.isend, fb, 0)]
+            self.inflight[step_no] = dist.batch_isend_irecv(ops)
+            return
+        self._finish_pending()             # the previous step's transfer ran under this step's kernel
+        if self.rank == 0:
+            ops = [dist.P2POp(dist.irecv, buf, r) for r, buf in self.pg.staging.items()]
+            self.scatter_to = fb
         else:
-            if self.rank == 0:
-                ops = [dist.P2POp(dist.irecv, buf, r) for r, buf in self.pg.staging.items()]
-                self.scatter_to = fb
-            else:
-                ops = [dist.P2POp(dist.isend, fb[:self.pg.n_rows[self.rank]], 0)] if self.pg.n_rows[self.rank] else []
+            ops = [dist.P2POp(dist.isend, fb[:self.pg.n_rows[self.rank]], 0)] if self.pg.n_rows[self.rank] else []
         if ops:
             self.pending = dist.batch_isend_irecv(ops)
 
