@@ -343,9 +343,25 @@ def main():
                                    "ms_per_frame_pageable": round(pageable_ms, 4),
                                    "what": "the same frame through the synchronous mrt_render (never `value`): the kernel writes the pixels "
                                            "over PCIe into a page-locked caller buffer (mrt_host_alloc) while it renders; `pageable`: any "
-                                           "other caller buffer, via a device frame, page-locked staging and one more memcpy"}
+                                           "other caller buffer, via a device frame, page-locked staging and one more memcpy; `pipelined`: mrt_render_submit / "
+                                           "mrt_render_wait with two page-locked frames, the copy of frame i under the rendering of frame i+1"}
         assert np.array_equal(hf.array, fbh)
+        # the same with the next frame in flight: mrt_render_submit / mrt_render_wait, two page-locked frames
+        hf2 = HostFrame(H, W)
+        ring, prev = [hf, hf2], None
+        for i in range(104):                  # 4 untimed frames: device frames, events and the copy stream are created on first use
+            if i == 4:
+                head.rt.wait(prev)
+                prev, t0 = None, time.perf_counter()
+            tk = head.rt.submit(cam, ring[i % 2].array, mode=MODE_RECURSIVE)
+            if prev is not None:
+                head.rt.wait(prev)
+            prev = tk
+        head.rt.wait(prev)
+        out["host_framebuffer"]["ms_per_frame_pipelined"] = round((time.perf_counter() - t0) / 100 * 1e3, 4)
+        assert np.array_equal(hf.array, fbh) and np.array_equal(hf2.array, fbh)
         hf.close()
+        hf2.close()
         # The persistent kernel starts the tiles first that were expensive in the previous frame, so a camera at
         # rest is its best case.  The same workload with the camera walking sideways at the frame loop's speed
         # (10 units/s, game.cpp:57-62) at 60 frames/s, 25 frames there and 25 back:

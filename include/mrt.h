@@ -122,6 +122,20 @@ int mrt_render(mrt_ctx* ctx, const float cam_to_world[16], uint32_t flags,
 void* mrt_host_alloc(size_t bytes);
 void mrt_host_free(void* p);
 
+/* The frame loop with the next frame in flight.  The reference's loop is Tick (which renders)
+ * followed by presenting the Surface (template.cpp:111-127); with these two calls the caller
+ * presents frame i while frame i+1 renders.  mrt_render_submit is mrt_render without hit IDs that
+ * returns once the frame is queued: fb MUST lie in page-locked memory (mrt_host_alloc; MRT_E_ARG
+ * otherwise) and must not be read, written or freed until mrt_render_wait(ticket) has returned
+ * for the ticket handed back.  Frames complete in submission order.  Up to MRT_MAX_IN_FLIGHT
+ * frames may be queued; one more fails with MRT_E_STATE.  mrt_render_wait reports MRT_E_LIMIT if
+ * that frame exhausted a traversal budget.  mrt_get_ray_counts refers to the frame submitted
+ * last.  mrt_destroy waits for queued frames. */
+#define MRT_MAX_IN_FLIGHT 4
+int mrt_render_submit(mrt_ctx* ctx, const float cam_to_world[16], uint32_t flags,
+                      uint32_t* fb, int pitch_px, int* ticket);
+int mrt_render_wait(mrt_ctx* ctx, int ticket);
+
 /* Same frame, device-resident and asynchronous: renders tile rows [y_begin, y_end) (multiples
  * of 8) into DEVICE memory fb_dev (row y at fb_dev + y*pitch_px) on `stream` (a hipStream_t,
  * NULL = the default stream) and returns without synchronising.  This is the launch the

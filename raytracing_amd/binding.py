@@ -19,7 +19,7 @@ MODE_RECURSIVE = 1
 
 SYMBOLS = ("mrt_create", "mrt_destroy", "mrt_last_error", "mrt_version", "mrt_scene_upload", "mrt_scene_upload_lbvh",
            "mrt_set_lights",
-           "mrt_bvh_build_host", "mrt_render", "mrt_host_alloc", "mrt_host_free", "mrt_render_device", "mrt_render_device_part", "mrt_part_rows",
+           "mrt_bvh_build_host", "mrt_render", "mrt_host_alloc", "mrt_host_free", "mrt_render_submit", "mrt_render_wait", "mrt_render_device", "mrt_render_device_part", "mrt_part_rows",
            "mrt_raster_render", "mrt_trace_packets",
            "mrt_trace_rays", "mrt_get_ray_counts", "mrt_camera_look_at")
 
@@ -81,6 +81,8 @@ def lib():
         L.mrt_host_alloc.restype = vp
         L.mrt_host_free.argtypes = [vp]
         L.mrt_host_free.restype = None
+        L.mrt_render_submit.argtypes = [vp, vp, C.c_uint32, vp, i32, C.POINTER(i32)]
+        L.mrt_render_wait.argtypes = [vp, i32]
         L.mrt_render_device_part.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, i32, vp, i32, vp, vp]
         L.mrt_part_rows.argtypes = [i32, i32, i32, i32]
         L.mrt_raster_render.argtypes = [vp, vp, vp, i32, vp, vp]
@@ -241,6 +243,18 @@ class Raytracer:
                                                   1 if compact else 0, C.c_void_p(fb_ptr), pitch,
                                                   C.c_void_p(ids_ptr) if ids_ptr else None,
                                                   C.c_void_p(stream) if stream else None), "mrt_render_device_part")
+
+    def submit(self, cam, fb, mode=MODE_PACKET, spp_grid=1):
+        """Queues one frame into a page-locked frame (HostFrame.array) and returns its ticket: mrt_render_submit."""
+        cam = np.ascontiguousarray(getattr(cam, "transform", cam), np.float32).reshape(16)
+        ticket = C.c_int32(-1)
+        self._check(self.L.mrt_render_submit(self.h, _p(cam), flags(mode, spp_grid), _p(fb), fb.strides[0] // 4, C.byref(ticket)),
+                    "mrt_render_submit")
+        return int(ticket.value)
+
+    def wait(self, ticket):
+        """Blocks until the frame with this ticket has landed in its page-locked frame: mrt_render_wait."""
+        self._check(self.L.mrt_render_wait(self.h, ticket), "mrt_render_wait")
 
     def ray_counts(self):
         out = np.zeros(4, np.uint64)

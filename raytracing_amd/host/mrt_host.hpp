@@ -356,6 +356,16 @@ public:
     void RenderRaster(const Camera& camera) {
         check(mrt_raster_render(ctx_, camera.transform, screen_->GetBuffer(), screen_->GetPitch(), nullptr, nullptr), "mrt_raster_render");
     }
+    // The frame loop with the next frame in flight (template.cpp:111-127 presents the Surface after Tick):
+    // Submit queues a frame into `target` (page-locked, as every Surface here is) and returns a ticket;
+    // Wait returns when that frame has landed.
+    int Submit(const Camera& camera, Surface* target, bool recursive) {
+        int ticket = -1;
+        check(mrt_render_submit(ctx_, camera.transform, recursive ? MRT_MODE_RECURSIVE : MRT_MODE_PACKET, target->GetBuffer(),
+                                target->GetPitch(), &ticket), "mrt_render_submit");
+        return ticket;
+    }
+    void Wait(int ticket) { check(mrt_render_wait(ctx_, ticket), "mrt_render_wait"); }
     void RayCounts(uint64_t out[4]) { check(mrt_get_ray_counts(ctx_, out), "mrt_get_ray_counts"); }
     mrt_ctx* Context() { return ctx_; }
 

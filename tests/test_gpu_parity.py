@@ -459,6 +459,35 @@ def test_tile_order_from_previous_frame_changes_nothing(maze_scene, monkeypatch,
     rt.close()
 
 
+def test_submit_and_wait_keep_frames_in_flight(maze_scene):
+    """mrt_render_submit / mrt_render_wait: four frames queued at once land in their page-locked frames
+    identical to what the synchronous mrt_render gives; a fifth is refused until one has been waited for."""
+    from raytracing_amd.binding import HostFrame
+    W, H = 640, 360
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(maze_scene)
+    cams = [pose_cam(p) for p in POSES[:4]]
+    want = [rt.render(c, mode=MODE_RECURSIVE, want_ids=False)[0].copy() for c in cams]
+    frames = [HostFrame(H, W) for _ in cams]
+    tickets = [rt.submit(c, f.array, mode=MODE_RECURSIVE) for c, f in zip(cams, frames)]
+    assert tickets == sorted(tickets) and len(set(tickets)) == 4
+    with pytest.raises(MrtError):
+        rt.submit(cams[0], frames[0].array, mode=MODE_RECURSIVE)          # MRT_MAX_IN_FLIGHT reached
+    for t, f, w in zip(tickets, frames, want):
+        rt.wait(t)
+        assert np.array_equal(f.array, w)
+    with pytest.raises(MrtError):
+        rt.wait(tickets[0])                                               # waited for already
+    with pytest.raises(MrtError):
+        rt.submit(cams[0], np.zeros((H, W), np.uint32), mode=MODE_PACKET)  # pageable memory
+    t = rt.submit(cams[1], frames[0].array, mode=MODE_PACKET)             # slots are reusable
+    rt.wait(t)
+    assert np.array_equal(frames[0].array, rt.render(cams[1], mode=MODE_PACKET, want_ids=False)[0])
+    for f in frames:
+        f.close()
+    rt.close()
+
+
 def test_error_paths(maze_scene):
     rt = Raytracer(64, 64, device=0)
     with pytest.raises(MrtError, match="scene_upload"):
@@ -474,16 +503,18 @@ def test_error_paths(maze_scene):
     rt.close()
 
 
-def test_cpp_host_driver_renders_reference_frame(tmp_path, known):
+@pytest.mark.parametrize("loop", [["--frames", "2"], ["--frames", "5", "--pipeline"]], ids=["synchronous", "pipelined"])
+def test_cpp_host_driver_renders_reference_frame(tmp_path, known, loop):
     """The headless C++ driver (Game::Init + Tick order through the host mirror classes) writes the
-    frame whose hash the reference recorded: 800x600, default camera, packet path."""
+    frame whose hash the reference recorded: 800x600, default camera, packet path; also with the next
+    frame kept in flight while the previous one is presented."""
     import os
     import subprocess
     from conftest import ROOT
     exe = os.path.join(ROOT, "raytracing_amd", "host", "mrt_game")
     out = str(tmp_path / "frame.ppm")
-    subprocess.check_call([exe, "--scene", os.path.join(ROOT, "tests", "golden", "maze.mrts"), "--size", "800", "600", "--frames", "2",
-                           "--mode", "packet", "--out", out])
+    subprocess.check_call([exe, "--scene", os.path.join(ROOT, "tests", "golden", "maze.mrts"), "--size", "800", "600",
+                           "--mode", "packet", "--out", out] + loop)
     with open(out, "rb") as f:
         assert f.readline() == b"P6\n" and f.readline() == b"800 600\n" and f.readline() == b"255\n"
         rgb = np.frombuffer(f.read(), np.uint8).reshape(600, 800, 3).astype(np.uint32)
