@@ -64,8 +64,9 @@ class Workload:
     other than 0 render their share packed and send it, rank 0 renders in place and scatters what
     it receives (multigpu.PartGather).
     split = "rows" double-buffers: the transfer of step i overlaps the rendering of step i+1.
-    split = "frames" uses three buffers and waits for the transfer of step i only before step i+3
-    renders into the same buffer.  The persistent frame kernel takes every CU's whole register file,
+    split = "frames" uses four buffers and waits for the transfer of step i only before step i+4
+    renders into the same buffer (one frame for the sender's kernel to get onto a CU, one for the
+    receiver's, one of slack: the frames of different GPUs are not in step).  The persistent frame kernel takes every CU's whole register file,
     so a send/recv kernel issued behind a frame cannot start before the NEXT frame boundary (measured
     with a stand-in kernel: scripts/native/coresidency.hip); with two buffers every frame would wait
     for a transfer that could only begin when the frame before it had ended."""
@@ -83,7 +84,7 @@ class Workload:
         self.events, self.pending, self.i = [], [], 0
         self.inflight = {}                 # split == "frames": step index -> transfers that read that step's buffer
         if world == 1 or split == "frames":
-            self.fb = [torch.zeros((height, width), dtype=torch.int32, device=device) for _ in range(3 if world > 1 else 1)]
+            self.fb = [torch.zeros((height, width), dtype=torch.int32, device=device) for _ in range(4 if world > 1 else 1)]
             self.frames = torch.zeros((world, height, width), dtype=torch.int32, device=device) if (world > 1 and rank == 0) else None
         else:
             self.pg = PartGather(height, width, world, rank, 1, torch, device, torch.int32)
