@@ -811,7 +811,10 @@ __global__ __launch_bounds__(64, MODE == 0 ? MRT_PACKET_WAVES : MRT_RECURSIVE_WA
 // LDS: nodes | triA | triB | triC | per-lane stacks (16 bit entries: a resident scene has
 // fewer than 65536 node slots).
 template <int MODE>
-__global__ __launch_bounds__(kResidentThreads) void render_tiles_resident(SceneDev S, FrameDev F) {
+#ifndef MRT_RESIDENT_WAVES
+#define MRT_RESIDENT_WAVES 4
+#endif
+__global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_tiles_resident(SceneDev S, FrameDev F) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t n_node_v4 = 2u * (uint32_t)S.n_node_slots, n_tri = (uint32_t)S.n_tris;
     MRT_LDS v4f* l_nodes = (MRT_LDS v4f*)smem;
