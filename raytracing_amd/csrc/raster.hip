@@ -220,9 +220,25 @@ __device__ __forceinline__ TileRange tile_range(const RasterTri& T) {
 
 // FILL = false: count the triangles of every tile, and list the big triangles.  FILL = true: write the
 // tiles' triangle lists (tile_start from the scan; cursor = running fill position per tile).
+// A tile's list is filled from both ends: triangles nearer than `near_thr` (1/z at the middle of their
+// bounding box; more negative = nearer) from the front, the others from the back.  The tile kernel
+// walks the list front to back, so the near ones lower the blocks' depth bounds before the far ones
+// are met, most of which are then skipped block by block.  The order changes no pixel.
+__device__ __forceinline__ bool is_near(const RasterTri& T, float near_thr) {
+    const float cx = 0.5f * (float)(T.x0 + T.x1), cy = 0.5f * (float)(T.y0 + T.y1);
+    return T.zA * cx + T.zB * cy + T.zC < near_thr;
+}
+template <bool FILL>
+__device__ __forceinline__ void bin_one(uint32_t t, uint32_t tile, bool front, uint32_t* tile_count, uint32_t* tile_back,
+                                        const uint32_t* tile_start, uint32_t* pairs) {
+    if (!FILL) { atomicAdd(&tile_count[tile], 1u); return; }
+    if (front) pairs[tile_start[tile] + atomicAdd(&tile_count[tile], 1u)] = t;
+    else pairs[tile_start[tile + 1] - 1u - atomicAdd(&tile_back[tile], 1u)] = t;
+}
 template <bool FILL>
 __global__ __launch_bounds__(256) void raster_bin_small(const RasterTri* setup, uint32_t n_tris, int tiles_x, uint32_t* tile_count,
-                                                         const uint32_t* tile_start, uint32_t* pairs, uint32_t* big, uint32_t* big_count) {
+                                                         uint32_t* tile_back, const uint32_t* tile_start, uint32_t* pairs, uint32_t* big,
+                                                         uint32_t* big_count, float near_thr) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tris) return;
     const RasterTri& T = setup[t];
@@ -232,26 +248,23 @@ __global__ __launch_bounds__(256) void raster_bin_small(const RasterTri* setup, 
         if (!FILL) big[atomicAdd(big_count, 1u)] = t;
         return;
     }
+    const bool front = FILL && is_near(T, near_thr);
     for (int j = 0; j < r.th; ++j)
-        for (int i = 0; i < r.tw; ++i) {
-            const uint32_t tile = (uint32_t)((r.ty0 + j) * tiles_x + r.tx0 + i);
-            const uint32_t slot = atomicAdd(&tile_count[tile], 1u);
-            if (FILL) pairs[tile_start[tile] + slot] = t;
-        }
+        for (int i = 0; i < r.tw; ++i)
+            bin_one<FILL>(t, (uint32_t)((r.ty0 + j) * tiles_x + r.tx0 + i), front, tile_count, tile_back, tile_start, pairs);
 }
 template <bool FILL>
-__global__ __launch_bounds__(256) void raster_bin_big(const RasterTri* setup, int tiles_x, uint32_t* tile_count, const uint32_t* tile_start,
-                                                       uint32_t* pairs, const uint32_t* big, const uint32_t* big_count) {
+__global__ __launch_bounds__(256) void raster_bin_big(const RasterTri* setup, int tiles_x, uint32_t* tile_count, uint32_t* tile_back,
+                                                       const uint32_t* tile_start, uint32_t* pairs, const uint32_t* big,
+                                                       const uint32_t* big_count, float near_thr) {
     const uint32_t n = *big_count;
     const int lane = threadIdx.x & 63;
     for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += kBigWaves) {
         const uint32_t t = big[i];
         const TileRange r = tile_range(setup[t]);
-        for (int k = lane; k < r.tw * r.th; k += 64) {
-            const uint32_t tile = (uint32_t)((r.ty0 + k / r.tw) * tiles_x + r.tx0 + k % r.tw);
-            const uint32_t slot = atomicAdd(&tile_count[tile], 1u);
-            if (FILL) pairs[tile_start[tile] + slot] = t;
-        }
+        const bool front = FILL && is_near(setup[t], near_thr);
+        for (int k = lane; k < r.tw * r.th; k += 64)
+            bin_one<FILL>(t, (uint32_t)((r.ty0 + k / r.tw) * tiles_x + r.tx0 + k % r.tw), front, tile_count, tile_back, tile_start, pairs);
     }
 }
 // exclusive scan of the tile counts by one workgroup; total[0] receives the number of (tile, triangle) pairs
@@ -277,8 +290,18 @@ __global__ __launch_bounds__(256) void raster_tile(const RasterTri* setup, const
                                                    RasterTextures tx, uint32_t* fb, int fb_pitch, int keep_uncovered, float* zbuf, int32_t* ids,
                                                    int W, int H) {
     __shared__ unsigned long long cell[kTile * kTile];
+    // Per 8x8 block of the tile: an upper bound of the depth keys its 64 cells hold.  Cells only ever
+    // decrease, so a maximum read at any time stays an upper bound; a triangle whose smallest 1/z over
+    // the block is above it cannot win any of the block's pixels (equal 1/z is not skipped: the lower
+    // triangle index wins ties) and the block is not tested at all.  1/z is evaluated as
+    // (zA*x + zB*y) + zC with every operation rounded, which is monotone in x and in y, so its
+    // minimum over the block is taken at a corner, in exactly the arithmetic of the per-pixel test.
+    __shared__ unsigned int block_max[(kTile / 8) * (kTile / 8)];
+    __shared__ unsigned int tile_max;                 // the same bound over the whole tile: one test skips a far triangle altogether
     const unsigned long long empty = ((unsigned long long)orderable(0.0f) << 32) | 0xffffffffull;   // the cleared z-buffer, no triangle
     for (int p = threadIdx.x; p < kTile * kTile; p += 256) cell[p] = empty;
+    if (threadIdx.x < (kTile / 8) * (kTile / 8)) block_max[threadIdx.x] = orderable(0.0f);
+    if (threadIdx.x == 0) tile_max = orderable(0.0f);
     __syncthreads();
     const int tile = blockIdx.x, px0 = (tile % tiles_x) << kTileShift, py0 = (tile / tiles_x) << kTileShift;
     const int lane = threadIdx.x & 63;
@@ -288,15 +311,41 @@ __global__ __launch_bounds__(256) void raster_tile(const RasterTri* setup, const
         const RasterTri& T = setup[t];
         const int bx0 = max(T.x0, px0) >> 3, bx1 = min(T.x1, px0 + kTile - 1) >> 3;
         const int by0 = max(T.y0, py0) >> 3, by1 = min(T.y1, py0 + kTile - 1) >> 3;
+        {
+            const float xa = (float)(bx0 << 3), xb = (float)((bx1 << 3) + 7), ya = (float)(by0 << 3), yb = (float)((by1 << 3) + 7);
+            const float c0 = T.zA * xa + T.zB * ya + T.zC, c1 = T.zA * xb + T.zB * ya + T.zC;
+            const float c2 = T.zA * xa + T.zB * yb + T.zC, c3 = T.zA * xb + T.zB * yb + T.zC;
+            const float zmin = fminf(fminf(c0, c1), fminf(c2, c3));
+            if (zmin == zmin && orderable(zmin) > tile_max) continue;
+        }
         for (int by = by0; by <= by1; ++by)
             for (int bx = bx0; bx <= bx1; ++bx) {
+                const int blk = (by - (py0 >> 3)) * (kTile / 8) + (bx - (px0 >> 3));
+                {
+                    const float xa = (float)(bx << 3), xb = (float)((bx << 3) + 7), ya = (float)(by << 3), yb = (float)((by << 3) + 7);
+                    const float c0 = T.zA * xa + T.zB * ya + T.zC, c1 = T.zA * xb + T.zB * ya + T.zC;
+                    const float c2 = T.zA * xa + T.zB * yb + T.zC, c3 = T.zA * xb + T.zB * yb + T.zC;
+                    const float zmin = fminf(fminf(c0, c1), fminf(c2, c3));
+                    if (zmin == zmin && orderable(zmin) > block_max[blk]) continue;      // wave-uniform; a NaN decides nothing
+                }
                 const int x = (bx << 3) + (lane & 7), y = (by << 3) + (lane >> 3);
-                if (x < T.x0 || x > T.x1 || y < T.y0 || y > T.y1) continue;
-                if (!covers(T, x, y, W)) continue;
-                const float z0 = T.zA * (float)x + T.zB * (float)y + T.zC;
-                if (!(z0 < 0.0f)) continue;             // the z-buffer is cleared to 0 and the test is "z0 >= zbuf: skip" (:55, :177)
-                const unsigned long long key = ((unsigned long long)orderable(z0) << 32) | t;
-                atomicMin(&cell[(y - py0) * kTile + (x - px0)], key);
+                bool won = false;
+                if (!(x < T.x0 || x > T.x1 || y < T.y0 || y > T.y1) && covers(T, x, y, W)) {
+                    const float z0 = T.zA * (float)x + T.zB * (float)y + T.zC;
+                    if (z0 < 0.0f) {                    // the z-buffer is cleared to 0 and the test is "z0 >= zbuf: skip" (:55, :177)
+                        const unsigned long long key = ((unsigned long long)orderable(z0) << 32) | t;
+                        won = key < atomicMin(&cell[(y - py0) * kTile + (x - px0)], key);
+                    }
+                }
+                if (__any(won)) {
+                    // some cell of the block went down: a new bound from what the cells hold now
+                    unsigned int m = (unsigned int)(cell[(((by << 3) - py0) + (lane >> 3)) * kTile + ((bx << 3) - px0) + (lane & 7)] >> 32);
+                    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o, 64));
+                    if (lane == 0) atomicMin(&block_max[blk], m);
+                    unsigned int tm = block_max[lane & 15];          // lane 0's update included: LDS operations of a wave complete in order
+                    for (int o = 8; o > 0; o >>= 1) tm = max(tm, (unsigned int)__shfl_xor((int)tm, o, 64));
+                    if (lane == 0) atomicMin(&tile_max, tm);
+                }
             }
     }
     __syncthreads();
@@ -318,7 +367,7 @@ __global__ __launch_bounds__(256) void raster_tile(const RasterTri* setup, const
 
 void raster_release(RasterState& R) {
     for (void* p : {(void*)R.d_pos, (void*)R.d_uv, (void*)R.d_N, (void*)R.d_tri, (void*)R.d_tri_tex, (void*)R.d_setup,
-                    (void*)R.d_pairs, (void*)R.d_chunk_base, (void*)R.d_total, (void*)R.d_tile_count, (void*)R.d_tile_start,
+                    (void*)R.d_pairs, (void*)R.d_chunk_base, (void*)R.d_total, (void*)R.d_tile_count, (void*)R.d_tile_start, (void*)R.d_tile_back,
                     (void*)R.d_fb, (void*)R.d_z, (void*)R.d_ids})
         if (p) (void)hipFree(p);
     if (R.h_stage) (void)hipHostFree(R.h_stage);
@@ -403,6 +452,8 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
     frustum_planes(W, H, frustum);
     // per-mesh frustum cull (rasterizer.cpp:92-98) and the "texture required" rule (:102)
     std::vector<int32_t> tri_tex(R.n_tris, -1);
+    double depth_sum = 0.0;
+    size_t depth_n = 0;
     for (size_t m = 0; m < R.meshes.size(); ++m) {
         const RasterMeshHost& h = R.meshes[m];
         bool visible = h.tris > 0 && h.texture >= 0;
@@ -419,8 +470,17 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
                 if (i == 8) visible = false;
             }
         }
-        if (visible) std::fill(tri_tex.begin() + h.tri_off, tri_tex.begin() + h.tri_off + h.tris, h.texture);
+        if (visible) {
+            std::fill(tri_tex.begin() + h.tri_off, tri_tex.begin() + h.tri_off + h.tris, h.texture);
+            const f4 mid = mul(M, f4{0.5f * (h.bounds[0].x + h.bounds[1].x), 0.5f * (h.bounds[0].y + h.bounds[1].y),
+                                     0.5f * (h.bounds[0].z + h.bounds[1].z), 1});
+            depth_sum += (double)mid.z * h.tris; depth_n += h.tris;
+        }
     }
+    // "near" for the fill order of the tile lists: in front of the triangle-weighted middle of the visible meshes
+    // (view space looks down -z; 1/z of a nearer point is more negative).  Only a heuristic for the order.
+    const double mid_z = depth_n > 0 ? depth_sum / (double)depth_n : 0.0;
+    const float near_thr = mid_z < -1e-6 ? (float)(1.0 / mid_z) : -INFINITY;
     RasterFrame F;
     memcpy(F.M, &M, 64);
     for (int p = 0; p < 2; ++p) { F.frustum[p][0] = frustum[p].x; F.frustum[p][1] = frustum[p].y; F.frustum[p][2] = frustum[p].z; F.frustum[p][3] = frustum[p].w; }
@@ -428,8 +488,9 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
     const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile;
     const uint32_t n_tiles = (uint32_t)(tiles_x * tiles_y);
     if (R.n_tile_slots < n_tiles + 1) {
-        for (void* p : {(void*)R.d_tile_count, (void*)R.d_tile_start}) if (p) (void)hipFree(p);
-        R.d_tile_count = nullptr; R.d_tile_start = nullptr; R.n_tile_slots = 0;
+        for (void* p : {(void*)R.d_tile_count, (void*)R.d_tile_start, (void*)R.d_tile_back}) if (p) (void)hipFree(p);
+        R.d_tile_count = nullptr; R.d_tile_start = nullptr; R.d_tile_back = nullptr; R.n_tile_slots = 0;
+        RASTER_HIP(hipMalloc((void**)&R.d_tile_back, (size_t)(n_tiles + 1) * 4));
         RASTER_HIP(hipMalloc((void**)&R.d_tile_count, (size_t)(n_tiles + 1) * 4));
         RASTER_HIP(hipMalloc((void**)&R.d_tile_start, (size_t)(n_tiles + 1) * 4));
         R.n_tile_slots = n_tiles + 1;
@@ -441,10 +502,10 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
         RASTER_HIP(hipMemcpyAsync(R.d_tri_tex, tri_tex.data(), (size_t)R.n_tris * 4, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(raster_setup, per_tri, b256, 0, stream, F, R.d_pos, R.d_uv, R.d_N, R.d_tri, R.d_tri_tex, R.d_setup, R.n_tris);
         RASTER_HIP(hipMemsetAsync(R.d_total, 0, 16, stream));          // [0] pairs, [1] big triangles
-        hipLaunchKernelGGL((raster_bin_small<false>), per_tri, b256, 0, stream, R.d_setup, R.n_tris, tiles_x, R.d_tile_count, R.d_tile_start,
-                           (uint32_t*)nullptr, R.d_chunk_base, R.d_total + 1);
-        hipLaunchKernelGGL((raster_bin_big<false>), dim3(kBigWaves / 4), b256, 0, stream, R.d_setup, tiles_x, R.d_tile_count, R.d_tile_start,
-                           (uint32_t*)nullptr, R.d_chunk_base, R.d_total + 1);
+        hipLaunchKernelGGL((raster_bin_small<false>), per_tri, b256, 0, stream, R.d_setup, R.n_tris, tiles_x, R.d_tile_count, R.d_tile_back,
+                           R.d_tile_start, (uint32_t*)nullptr, R.d_chunk_base, R.d_total + 1, near_thr);
+        hipLaunchKernelGGL((raster_bin_big<false>), dim3(kBigWaves / 4), b256, 0, stream, R.d_setup, tiles_x, R.d_tile_count, R.d_tile_back,
+                           R.d_tile_start, (uint32_t*)nullptr, R.d_chunk_base, R.d_total + 1, near_thr);
         hipLaunchKernelGGL(raster_tile_scan, dim3(1), dim3(1024), 0, stream, R.d_tile_count, R.d_tile_start, n_tiles, R.d_total);
         uint32_t n_pairs = 0;
         RASTER_HIP(hipMemcpyAsync(&n_pairs, R.d_total, 4, hipMemcpyDeviceToHost, stream));
@@ -458,10 +519,11 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
         }
         if (n_pairs > 0) {
             RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_tiles + 1) * 4, stream));      // now the fill cursors
-            hipLaunchKernelGGL((raster_bin_small<true>), per_tri, b256, 0, stream, R.d_setup, R.n_tris, tiles_x, R.d_tile_count, R.d_tile_start,
-                               R.d_pairs, R.d_chunk_base, R.d_total + 1);
-            hipLaunchKernelGGL((raster_bin_big<true>), dim3(kBigWaves / 4), b256, 0, stream, R.d_setup, tiles_x, R.d_tile_count, R.d_tile_start,
-                               R.d_pairs, R.d_chunk_base, R.d_total + 1);
+            RASTER_HIP(hipMemsetAsync(R.d_tile_back, 0, (size_t)(n_tiles + 1) * 4, stream));
+            hipLaunchKernelGGL((raster_bin_small<true>), per_tri, b256, 0, stream, R.d_setup, R.n_tris, tiles_x, R.d_tile_count, R.d_tile_back,
+                               R.d_tile_start, R.d_pairs, R.d_chunk_base, R.d_total + 1, near_thr);
+            hipLaunchKernelGGL((raster_bin_big<true>), dim3(kBigWaves / 4), b256, 0, stream, R.d_setup, tiles_x, R.d_tile_count, R.d_tile_back,
+                               R.d_tile_start, R.d_pairs, R.d_chunk_base, R.d_total + 1, near_thr);
         }
     }
     // A frame in page-locked memory (mrt_host_alloc) is written by the kernel itself, covered pixels only; any
