@@ -45,6 +45,7 @@ struct RasterState {
     int32_t* d_tri = nullptr;        // per triangle, 3 vertex indices into d_pos/d_uv (already offset)
     int32_t* d_tri_tex = nullptr;    // per triangle: texture index, or -1 when its mesh is culled / untextured
     RasterTri* d_setup = nullptr;
+    uint2* d_bins = nullptr;          // per triangle: tile range, near / drawn flags (8 bytes; what the binning passes read)
     uint32_t* d_chunk_base = nullptr; // n_tris words: list of the triangles that overlap many tiles
     uint32_t* d_total = nullptr;     // [0] (tile, triangle) pairs this frame, [1] length of the big-triangle list
     uint32_t* d_tile_count = nullptr; // per 32x32 tile: triangle count, then fill cursor

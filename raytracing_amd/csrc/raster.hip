@@ -3,10 +3,12 @@
 //   raster_setup      one thread per triangle: vertex transform, back-face cull, Sutherland-Hodgman
 //                     clip against the near and left planes, projection, palette level, per-edge
 //                     constants and the screen-space plane equations of 1/z, u/z and v/z
-//                     (rasterizer.cpp:100-141).
-//   raster_bin_*      bin the triangles' pixel bounding boxes to 32x32-pixel screen tiles: count per
-//                     tile, exclusive scan, fill (a triangle overlapping more than 16 tiles is
-//                     binned by a whole wave, lanes striding over its tiles).
+//                     (rasterizer.cpp:100-141); it also counts the triangle into the 32x32-pixel
+//                     screen tiles its pixel bounding box overlaps.
+//   raster_tile_scan, raster_fill_small, raster_bin_big
+//                     exclusive scan of the tile counts, then the tiles' triangle lists are filled (a
+//                     triangle overlapping more than 16 tiles is counted and filled by a whole wave,
+//                     lanes striding over its tiles).
 //   raster_tile       one workgroup per tile, depth cells of the tile in LDS.  Each wave takes every
 //                     fourth triangle of the tile's list; one lane per pixel of an 8x8 block.  A
 //                     pixel is covered exactly when the reference's scan conversion would plot it
@@ -52,8 +54,35 @@ __device__ __forceinline__ f3 xform(const float* M, f3 p) {
     return {r.x, r.y, r.z};
 }
 
+constexpr int kTile = 32, kTileShift = 5;
+constexpr int kSmallTiles = 16;          // a triangle overlapping more tiles than this is binned by a whole wave
+constexpr int kBigWaves = 1024;
+
+struct TileRange { int tx0, ty0, tw, th; };
+__device__ __forceinline__ TileRange tile_range(const RasterTri& T) {
+    TileRange r;
+    r.tx0 = T.x0 >> kTileShift; r.ty0 = T.y0 >> kTileShift;
+    r.tw = (T.x1 >> kTileShift) - r.tx0 + 1; r.th = (T.y1 >> kTileShift) - r.ty0 + 1;
+    return r;
+}
+__device__ __forceinline__ bool is_near(const RasterTri& T, float near_thr) {
+    const float cx = 0.5f * (float)(T.x0 + T.x1), cy = 0.5f * (float)(T.y0 + T.y1);
+    return T.zA * cx + T.zB * cy + T.zC < near_thr;
+}
+// What binning needs of a triangle, 8 bytes instead of the 164-byte set-up record:
+// lo = first tile column | first tile row << 12 | near << 24 | drawn << 25, hi = tile columns | tile rows << 12
+__device__ __forceinline__ uint2 pack_bin(const TileRange& r, bool near) {
+    return make_uint2((uint32_t)r.tx0 | ((uint32_t)r.ty0 << 12) | (near ? 1u << 24 : 0u) | (1u << 25), (uint32_t)r.tw | ((uint32_t)r.th << 12));
+}
+__device__ __forceinline__ bool bin_drawn(uint2 b) { return (b.x >> 25) & 1u; }
+__device__ __forceinline__ bool bin_near(uint2 b) { return (b.x >> 24) & 1u; }
+__device__ __forceinline__ TileRange bin_range(uint2 b) {
+    return TileRange{(int)(b.x & 0xfffu), (int)((b.x >> 12) & 0xfffu), (int)(b.y & 0xfffu), (int)((b.y >> 12) & 0xfffu)};
+}
+
 __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* pos, const float* uv, const float* N, const int32_t* tri,
-                                                     const int32_t* tri_tex, RasterTri* out, uint32_t n_tris) {
+                                                     const int32_t* tri_tex, RasterTri* out, uint32_t n_tris, uint2* bins, int tiles_x,
+                                                     uint32_t* tile_count, uint32_t* big, uint32_t* big_count, float near_thr) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_tris) return;
     RasterTri T;
@@ -148,6 +177,13 @@ __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* 
         }
     }
     out[i] = T;
+    // binning, first pass: the triangle's tile range for the fill pass, and the tiles' triangle counts
+    if (T.n == 0) { bins[i] = make_uint2(0u, 0u); return; }
+    const TileRange r = tile_range(T);
+    bins[i] = pack_bin(r, is_near(T, near_thr));
+    if (r.tw * r.th > kSmallTiles) { big[atomicAdd(big_count, 1u)] = i; return; }
+    for (int j = 0; j < r.th; ++j)
+        for (int k = 0; k < r.tw; ++k) atomicAdd(&tile_count[(r.ty0 + j) * tiles_x + r.tx0 + k], 1u);
 }
 
 // Is pixel (x, y) plotted by the reference's scan conversion of this polygon?  The row extent of
@@ -206,28 +242,14 @@ __device__ __forceinline__ void resolve_pixel(const RasterTri* setup, unsigned l
 // atomic in memory, and resolves its own pixels.  The result is the same minimum over
 // {1/z, triangle index} per pixel, whatever the order in which a tile meets its triangles.
 // ---------------------------------------------------------------------------------------
-constexpr int kTile = 32, kTileShift = 5;
-constexpr int kSmallTiles = 16;          // a triangle overlapping more tiles than this is binned by a whole wave
-constexpr int kBigWaves = 1024;
 
-struct TileRange { int tx0, ty0, tw, th; };
-__device__ __forceinline__ TileRange tile_range(const RasterTri& T) {
-    TileRange r;
-    r.tx0 = T.x0 >> kTileShift; r.ty0 = T.y0 >> kTileShift;
-    r.tw = (T.x1 >> kTileShift) - r.tx0 + 1; r.th = (T.y1 >> kTileShift) - r.ty0 + 1;
-    return r;
-}
-
-// FILL = false: count the triangles of every tile, and list the big triangles.  FILL = true: write the
-// tiles' triangle lists (tile_start from the scan; cursor = running fill position per tile).
+// Binning in two passes.  Counting: raster_setup itself counts the triangles of every tile and lists the
+// big triangles, raster_bin_big<false> counts those.  Filling, after the scan has turned counts into list
+// starts: raster_fill_small and raster_bin_big<true> write the lists (cursor = running fill position per tile).
 // A tile's list is filled from both ends: triangles nearer than `near_thr` (1/z at the middle of their
 // bounding box; more negative = nearer) from the front, the others from the back.  The tile kernel
 // walks the list front to back, so the near ones lower the blocks' depth bounds before the far ones
 // are met, most of which are then skipped block by block.  The order changes no pixel.
-__device__ __forceinline__ bool is_near(const RasterTri& T, float near_thr) {
-    const float cx = 0.5f * (float)(T.x0 + T.x1), cy = 0.5f * (float)(T.y0 + T.y1);
-    return T.zA * cx + T.zB * cy + T.zC < near_thr;
-}
 template <bool FILL>
 __device__ __forceinline__ void bin_one(uint32_t t, uint32_t tile, bool front, uint32_t* tile_count, uint32_t* tile_back,
                                         const uint32_t* tile_start, uint32_t* pairs) {
@@ -235,34 +257,32 @@ __device__ __forceinline__ void bin_one(uint32_t t, uint32_t tile, bool front, u
     if (front) pairs[tile_start[tile] + atomicAdd(&tile_count[tile], 1u)] = t;
     else pairs[tile_start[tile + 1] - 1u - atomicAdd(&tile_back[tile], 1u)] = t;
 }
-template <bool FILL>
-__global__ __launch_bounds__(256) void raster_bin_small(const RasterTri* setup, uint32_t n_tris, int tiles_x, uint32_t* tile_count,
-                                                         uint32_t* tile_back, const uint32_t* tile_start, uint32_t* pairs, uint32_t* big,
-                                                         uint32_t* big_count, float near_thr) {
+// second pass for the triangles that overlap few tiles: one thread per triangle writes it into its tiles' lists
+__global__ __launch_bounds__(256) void raster_fill_small(const uint2* bins, uint32_t n_tris, int tiles_x, uint32_t* tile_count,
+                                                          uint32_t* tile_back, const uint32_t* tile_start, uint32_t* pairs) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tris) return;
-    const RasterTri& T = setup[t];
-    if (T.n == 0) return;
-    const TileRange r = tile_range(T);
-    if (r.tw * r.th > kSmallTiles) {
-        if (!FILL) big[atomicAdd(big_count, 1u)] = t;
-        return;
-    }
-    const bool front = FILL && is_near(T, near_thr);
+    const uint2 b = bins[t];
+    if (!bin_drawn(b)) return;
+    const TileRange r = bin_range(b);
+    if (r.tw * r.th > kSmallTiles) return;
+    const bool front = bin_near(b);
     for (int j = 0; j < r.th; ++j)
         for (int i = 0; i < r.tw; ++i)
-            bin_one<FILL>(t, (uint32_t)((r.ty0 + j) * tiles_x + r.tx0 + i), front, tile_count, tile_back, tile_start, pairs);
+            bin_one<true>(t, (uint32_t)((r.ty0 + j) * tiles_x + r.tx0 + i), front, tile_count, tile_back, tile_start, pairs);
 }
+// triangles that overlap many tiles, one wave each.  FILL = false: count; FILL = true: write the lists
 template <bool FILL>
-__global__ __launch_bounds__(256) void raster_bin_big(const RasterTri* setup, int tiles_x, uint32_t* tile_count, uint32_t* tile_back,
+__global__ __launch_bounds__(256) void raster_bin_big(const uint2* bins, int tiles_x, uint32_t* tile_count, uint32_t* tile_back,
                                                        const uint32_t* tile_start, uint32_t* pairs, const uint32_t* big,
-                                                       const uint32_t* big_count, float near_thr) {
+                                                       const uint32_t* big_count) {
     const uint32_t n = *big_count;
     const int lane = threadIdx.x & 63;
     for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += kBigWaves) {
         const uint32_t t = big[i];
-        const TileRange r = tile_range(setup[t]);
-        const bool front = FILL && is_near(setup[t], near_thr);
+        const uint2 b = bins[t];
+        const TileRange r = bin_range(b);
+        const bool front = FILL && bin_near(b);
         for (int k = lane; k < r.tw * r.th; k += 64)
             bin_one<FILL>(t, (uint32_t)((r.ty0 + k / r.tw) * tiles_x + r.tx0 + k % r.tw), front, tile_count, tile_back, tile_start, pairs);
     }
@@ -366,7 +386,7 @@ __global__ __launch_bounds__(256) void raster_tile(const RasterTri* setup, const
     } while (0)
 
 void raster_release(RasterState& R) {
-    for (void* p : {(void*)R.d_pos, (void*)R.d_uv, (void*)R.d_N, (void*)R.d_tri, (void*)R.d_tri_tex, (void*)R.d_setup,
+    for (void* p : {(void*)R.d_pos, (void*)R.d_uv, (void*)R.d_N, (void*)R.d_tri, (void*)R.d_tri_tex, (void*)R.d_setup, (void*)R.d_bins,
                     (void*)R.d_pairs, (void*)R.d_chunk_base, (void*)R.d_total, (void*)R.d_tile_count, (void*)R.d_tile_start, (void*)R.d_tile_back,
                     (void*)R.d_fb, (void*)R.d_z, (void*)R.d_ids})
         if (p) (void)hipFree(p);
@@ -405,6 +425,7 @@ int raster_upload(RasterState& R, const mrt_mesh* meshes, int n_meshes, hipStrea
     RASTER_HIP(hipMalloc((void**)&R.d_tri, tri.size() * 4));
     RASTER_HIP(hipMalloc((void**)&R.d_tri_tex, (size_t)R.n_tris * 4));
     RASTER_HIP(hipMalloc((void**)&R.d_setup, (size_t)R.n_tris * sizeof(RasterTri)));
+    RASTER_HIP(hipMalloc((void**)&R.d_bins, (size_t)R.n_tris * sizeof(uint2)));
     RASTER_HIP(hipMalloc((void**)&R.d_chunk_base, (size_t)R.n_tris * 4));
     RASTER_HIP(hipMalloc((void**)&R.d_total, 16));
     RASTER_HIP(hipMemcpyAsync(R.d_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, stream));
@@ -500,12 +521,11 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
     if (R.n_tris > 0) {
         const dim3 per_tri((R.n_tris + 255) / 256), b256(256);
         RASTER_HIP(hipMemcpyAsync(R.d_tri_tex, tri_tex.data(), (size_t)R.n_tris * 4, hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(raster_setup, per_tri, b256, 0, stream, F, R.d_pos, R.d_uv, R.d_N, R.d_tri, R.d_tri_tex, R.d_setup, R.n_tris);
         RASTER_HIP(hipMemsetAsync(R.d_total, 0, 16, stream));          // [0] pairs, [1] big triangles
-        hipLaunchKernelGGL((raster_bin_small<false>), per_tri, b256, 0, stream, R.d_setup, R.n_tris, tiles_x, R.d_tile_count, R.d_tile_back,
-                           R.d_tile_start, (uint32_t*)nullptr, R.d_chunk_base, R.d_total + 1, near_thr);
-        hipLaunchKernelGGL((raster_bin_big<false>), dim3(kBigWaves / 4), b256, 0, stream, R.d_setup, tiles_x, R.d_tile_count, R.d_tile_back,
-                           R.d_tile_start, (uint32_t*)nullptr, R.d_chunk_base, R.d_total + 1, near_thr);
+        hipLaunchKernelGGL(raster_setup, per_tri, b256, 0, stream, F, R.d_pos, R.d_uv, R.d_N, R.d_tri, R.d_tri_tex, R.d_setup, R.n_tris,
+                           R.d_bins, tiles_x, R.d_tile_count, R.d_chunk_base, R.d_total + 1, near_thr);
+        hipLaunchKernelGGL((raster_bin_big<false>), dim3(kBigWaves / 4), b256, 0, stream, R.d_bins, tiles_x, R.d_tile_count, R.d_tile_back,
+                           R.d_tile_start, (uint32_t*)nullptr, R.d_chunk_base, R.d_total + 1);
         hipLaunchKernelGGL(raster_tile_scan, dim3(1), dim3(1024), 0, stream, R.d_tile_count, R.d_tile_start, n_tiles, R.d_total);
         uint32_t n_pairs = 0;
         RASTER_HIP(hipMemcpyAsync(&n_pairs, R.d_total, 4, hipMemcpyDeviceToHost, stream));
@@ -520,10 +540,10 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
         if (n_pairs > 0) {
             RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_tiles + 1) * 4, stream));      // now the fill cursors
             RASTER_HIP(hipMemsetAsync(R.d_tile_back, 0, (size_t)(n_tiles + 1) * 4, stream));
-            hipLaunchKernelGGL((raster_bin_small<true>), per_tri, b256, 0, stream, R.d_setup, R.n_tris, tiles_x, R.d_tile_count, R.d_tile_back,
-                               R.d_tile_start, R.d_pairs, R.d_chunk_base, R.d_total + 1, near_thr);
-            hipLaunchKernelGGL((raster_bin_big<true>), dim3(kBigWaves / 4), b256, 0, stream, R.d_setup, tiles_x, R.d_tile_count, R.d_tile_back,
-                               R.d_tile_start, R.d_pairs, R.d_chunk_base, R.d_total + 1, near_thr);
+            hipLaunchKernelGGL(raster_fill_small, per_tri, b256, 0, stream, R.d_bins, R.n_tris, tiles_x, R.d_tile_count, R.d_tile_back,
+                               R.d_tile_start, R.d_pairs);
+            hipLaunchKernelGGL((raster_bin_big<true>), dim3(kBigWaves / 4), b256, 0, stream, R.d_bins, tiles_x, R.d_tile_count, R.d_tile_back,
+                               R.d_tile_start, R.d_pairs, R.d_chunk_base, R.d_total + 1);
         }
     }
     // A frame in page-locked memory (mrt_host_alloc) is written by the kernel itself, covered pixels only; any
