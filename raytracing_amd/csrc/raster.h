@@ -43,7 +43,8 @@ struct RasterState {
     float* d_uv = nullptr;           // 2 floats each
     float* d_N = nullptr;            // per triangle, 3 floats
     int32_t* d_tri = nullptr;        // per triangle, 3 vertex indices into d_pos/d_uv (already offset)
-    int32_t* d_tri_tex = nullptr;    // per triangle: texture index, or -1 when its mesh is culled / untextured
+    int32_t* d_tri_mesh = nullptr;   // per triangle: mesh index (uploaded once)
+    int32_t* d_mesh_tex = nullptr;   // per mesh, every frame: texture index, or -1 when the mesh is culled / untextured
     RasterTri* d_setup = nullptr;
     uint2* d_bins = nullptr;          // per triangle: tile range, near / drawn flags (8 bytes; what the binning passes read)
     uint32_t* d_chunk_base = nullptr; // n_tris words: list of the triangles that overlap many tiles
@@ -56,6 +57,7 @@ struct RasterState {
     size_t pair_capacity = 0;
     uint32_t n_verts = 0, n_tris = 0;
     std::vector<int32_t> h_tri_mesh; // per triangle: mesh index
+    std::vector<int32_t> h_mesh_tex; // host copy of d_mesh_tex for the frame being queued
     uint32_t* d_fb = nullptr;
     float* d_z = nullptr;
     int32_t* d_ids = nullptr;

@@ -81,13 +81,13 @@ __device__ __forceinline__ TileRange bin_range(uint2 b) {
 }
 
 __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* pos, const float* uv, const float* N, const int32_t* tri,
-                                                     const int32_t* tri_tex, RasterTri* out, uint32_t n_tris, uint2* bins, int tiles_x,
+                                                     const int32_t* tri_mesh, const int32_t* mesh_tex, RasterTri* out, uint32_t n_tris, uint2* bins, int tiles_x,
                                                      uint32_t* tile_count, uint32_t* big, uint32_t* big_count, float near_thr) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_tris) return;
     RasterTri T;
     T.n = 0;
-    const int texture = tri_tex[i];
+    const int texture = mesh_tex[tri_mesh[i]];       // -1 when the mesh is culled or has no texture
     if (texture >= 0) {
         const int W = F.W, H = F.H;
         m4 M;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void raster_tile(const RasterTri* setup, const
     } while (0)
 
 void raster_release(RasterState& R) {
-    for (void* p : {(void*)R.d_pos, (void*)R.d_uv, (void*)R.d_N, (void*)R.d_tri, (void*)R.d_tri_tex, (void*)R.d_setup, (void*)R.d_bins,
+    for (void* p : {(void*)R.d_pos, (void*)R.d_uv, (void*)R.d_N, (void*)R.d_tri, (void*)R.d_tri_mesh, (void*)R.d_mesh_tex, (void*)R.d_setup, (void*)R.d_bins,
                     (void*)R.d_pairs, (void*)R.d_chunk_base, (void*)R.d_total, (void*)R.d_tile_count, (void*)R.d_tile_start, (void*)R.d_tile_back,
                     (void*)R.d_fb, (void*)R.d_z, (void*)R.d_ids})
         if (p) (void)hipFree(p);
@@ -423,7 +423,9 @@ int raster_upload(RasterState& R, const mrt_mesh* meshes, int n_meshes, hipStrea
     RASTER_HIP(hipMalloc((void**)&R.d_uv, uv.size() * 4));
     RASTER_HIP(hipMalloc((void**)&R.d_N, N.size() * 4));
     RASTER_HIP(hipMalloc((void**)&R.d_tri, tri.size() * 4));
-    RASTER_HIP(hipMalloc((void**)&R.d_tri_tex, (size_t)R.n_tris * 4));
+    RASTER_HIP(hipMalloc((void**)&R.d_tri_mesh, (size_t)R.n_tris * 4));
+    RASTER_HIP(hipMalloc((void**)&R.d_mesh_tex, R.meshes.size() * 4));
+    RASTER_HIP(hipMemcpyAsync(R.d_tri_mesh, R.h_tri_mesh.data(), (size_t)R.n_tris * 4, hipMemcpyHostToDevice, stream));
     RASTER_HIP(hipMalloc((void**)&R.d_setup, (size_t)R.n_tris * sizeof(RasterTri)));
     RASTER_HIP(hipMalloc((void**)&R.d_bins, (size_t)R.n_tris * sizeof(uint2)));
     RASTER_HIP(hipMalloc((void**)&R.d_chunk_base, (size_t)R.n_tris * 4));
@@ -472,7 +474,7 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
     f4 frustum[5];
     frustum_planes(W, H, frustum);
     // per-mesh frustum cull (rasterizer.cpp:92-98) and the "texture required" rule (:102)
-    std::vector<int32_t> tri_tex(R.n_tris, -1);
+    R.h_mesh_tex.assign(R.meshes.size(), -1);
     double depth_sum = 0.0;
     size_t depth_n = 0;
     for (size_t m = 0; m < R.meshes.size(); ++m) {
@@ -492,7 +494,7 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
             }
         }
         if (visible) {
-            std::fill(tri_tex.begin() + h.tri_off, tri_tex.begin() + h.tri_off + h.tris, h.texture);
+            R.h_mesh_tex[m] = h.texture;
             const f4 mid = mul(M, f4{0.5f * (h.bounds[0].x + h.bounds[1].x), 0.5f * (h.bounds[0].y + h.bounds[1].y),
                                      0.5f * (h.bounds[0].z + h.bounds[1].z), 1});
             depth_sum += (double)mid.z * h.tris; depth_n += h.tris;
@@ -520,9 +522,9 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
     RASTER_HIP(hipMemsetAsync(R.d_tile_start, 0, (size_t)(n_tiles + 1) * 4, stream));
     if (R.n_tris > 0) {
         const dim3 per_tri((R.n_tris + 255) / 256), b256(256);
-        RASTER_HIP(hipMemcpyAsync(R.d_tri_tex, tri_tex.data(), (size_t)R.n_tris * 4, hipMemcpyHostToDevice, stream));
+        RASTER_HIP(hipMemcpyAsync(R.d_mesh_tex, R.h_mesh_tex.data(), R.h_mesh_tex.size() * 4, hipMemcpyHostToDevice, stream));
         RASTER_HIP(hipMemsetAsync(R.d_total, 0, 16, stream));          // [0] pairs, [1] big triangles
-        hipLaunchKernelGGL(raster_setup, per_tri, b256, 0, stream, F, R.d_pos, R.d_uv, R.d_N, R.d_tri, R.d_tri_tex, R.d_setup, R.n_tris,
+        hipLaunchKernelGGL(raster_setup, per_tri, b256, 0, stream, F, R.d_pos, R.d_uv, R.d_N, R.d_tri, R.d_tri_mesh, R.d_mesh_tex, R.d_setup, R.n_tris,
                            R.d_bins, tiles_x, R.d_tile_count, R.d_chunk_base, R.d_total + 1, near_thr);
         hipLaunchKernelGGL((raster_bin_big<false>), dim3(kBigWaves / 4), b256, 0, stream, R.d_bins, tiles_x, R.d_tile_count, R.d_tile_back,
                            R.d_tile_start, (uint32_t*)nullptr, R.d_chunk_base, R.d_total + 1);
@@ -577,7 +579,7 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
     unsigned char* ids_stage = next;
     if (tri_ids) next += npx * 4;
     if (zbuf) RASTER_HIP(hipMemcpyAsync(next, R.d_z, npx * 4, hipMemcpyDeviceToHost, stream));
-    RASTER_HIP(hipStreamSynchronize(stream));      // tri_tex goes out of scope after this
+    RASTER_HIP(hipStreamSynchronize(stream));      // also: h_mesh_tex may be rewritten by the next call only after its copy has been read
     if (!fb_direct)
         for (int y = 0; y < H; ++y) {
             const uint32_t* src = h_fb + (size_t)y * W;
