@@ -250,16 +250,19 @@ __device__ __forceinline__ void resolve_pixel(const RasterTri* setup, unsigned l
 // bounding box; more negative = nearer) from the front, the others from the back.  The tile kernel
 // walks the list front to back, so the near ones lower the blocks' depth bounds before the far ones
 // are met, most of which are then skipped block by block.  The order changes no pixel.
+// `capacity`: entries the pair buffer holds.  It was sized from an earlier frame; a frame that needs more is
+// rendered again after the buffer has grown, so entries past the end are only kept from being written.
 template <bool FILL>
 __device__ __forceinline__ void bin_one(uint32_t t, uint32_t tile, bool front, uint32_t* tile_count, uint32_t* tile_back,
-                                        const uint32_t* tile_start, uint32_t* pairs) {
+                                        const uint32_t* tile_start, uint32_t* pairs, uint32_t capacity) {
     if (!FILL) { atomicAdd(&tile_count[tile], 1u); return; }
-    if (front) pairs[tile_start[tile] + atomicAdd(&tile_count[tile], 1u)] = t;
-    else pairs[tile_start[tile + 1] - 1u - atomicAdd(&tile_back[tile], 1u)] = t;
+    const uint32_t at = front ? tile_start[tile] + atomicAdd(&tile_count[tile], 1u)
+                              : tile_start[tile + 1] - 1u - atomicAdd(&tile_back[tile], 1u);
+    if (at < capacity) pairs[at] = t;
 }
 // second pass for the triangles that overlap few tiles: one thread per triangle writes it into its tiles' lists
 __global__ __launch_bounds__(256) void raster_fill_small(const uint2* bins, uint32_t n_tris, int tiles_x, uint32_t* tile_count,
-                                                          uint32_t* tile_back, const uint32_t* tile_start, uint32_t* pairs) {
+                                                          uint32_t* tile_back, const uint32_t* tile_start, uint32_t* pairs, uint32_t capacity) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tris) return;
     const uint2 b = bins[t];
@@ -269,13 +272,13 @@ __global__ __launch_bounds__(256) void raster_fill_small(const uint2* bins, uint
     const bool front = bin_near(b);
     for (int j = 0; j < r.th; ++j)
         for (int i = 0; i < r.tw; ++i)
-            bin_one<true>(t, (uint32_t)((r.ty0 + j) * tiles_x + r.tx0 + i), front, tile_count, tile_back, tile_start, pairs);
+            bin_one<true>(t, (uint32_t)((r.ty0 + j) * tiles_x + r.tx0 + i), front, tile_count, tile_back, tile_start, pairs, capacity);
 }
 // triangles that overlap many tiles, one wave each.  FILL = false: count; FILL = true: write the lists
 template <bool FILL>
 __global__ __launch_bounds__(256) void raster_bin_big(const uint2* bins, int tiles_x, uint32_t* tile_count, uint32_t* tile_back,
                                                        const uint32_t* tile_start, uint32_t* pairs, const uint32_t* big,
-                                                       const uint32_t* big_count) {
+                                                       const uint32_t* big_count, uint32_t capacity) {
     const uint32_t n = *big_count;
     const int lane = threadIdx.x & 63;
     for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += kBigWaves) {
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256) void raster_bin_big(const uint2* bins, int til
         const TileRange r = bin_range(b);
         const bool front = FILL && bin_near(b);
         for (int k = lane; k < r.tw * r.th; k += 64)
-            bin_one<FILL>(t, (uint32_t)((r.ty0 + k / r.tw) * tiles_x + r.tx0 + k % r.tw), front, tile_count, tile_back, tile_start, pairs);
+            bin_one<FILL>(t, (uint32_t)((r.ty0 + k / r.tw) * tiles_x + r.tx0 + k % r.tw), front, tile_count, tile_back, tile_start, pairs, capacity);
     }
 }
 // exclusive scan of the tile counts by one workgroup; total[0] receives the number of (tile, triangle) pairs
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(1024) void raster_tile_scan(const uint32_t* tile_co
 
 __global__ __launch_bounds__(256) void raster_tile(const RasterTri* setup, const uint32_t* tile_start, const uint32_t* pairs, int tiles_x,
                                                    RasterTextures tx, uint32_t* fb, int fb_pitch, int keep_uncovered, float* zbuf, int32_t* ids,
-                                                   int W, int H) {
+                                                   int W, int H, uint32_t capacity) {
     __shared__ unsigned long long cell[kTile * kTile];
     // Per 8x8 block of the tile: an upper bound of the depth keys its 64 cells hold.  Cells only ever
     // decrease, so a maximum read at any time stays an upper bound; a triangle whose smallest 1/z over
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256) void raster_tile(const RasterTri* setup, const
     __syncthreads();
     const int tile = blockIdx.x, px0 = (tile % tiles_x) << kTileShift, py0 = (tile / tiles_x) << kTileShift;
     const int lane = threadIdx.x & 63;
-    const uint32_t begin = tile_start[tile], end = tile_start[tile + 1];
+    const uint32_t begin = tile_start[tile], end = min(tile_start[tile + 1], capacity);
     for (uint32_t i = begin + (threadIdx.x >> 6); i < end; i += 4) {
         const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)pairs[i]);
         const RasterTri& T = setup[t];
@@ -527,26 +530,8 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
         hipLaunchKernelGGL(raster_setup, per_tri, b256, 0, stream, F, R.d_pos, R.d_uv, R.d_N, R.d_tri, R.d_tri_mesh, R.d_mesh_tex, R.d_setup, R.n_tris,
                            R.d_bins, tiles_x, R.d_tile_count, R.d_chunk_base, R.d_total + 1, near_thr);
         hipLaunchKernelGGL((raster_bin_big<false>), dim3(kBigWaves / 4), b256, 0, stream, R.d_bins, tiles_x, R.d_tile_count, R.d_tile_back,
-                           R.d_tile_start, (uint32_t*)nullptr, R.d_chunk_base, R.d_total + 1);
+                           R.d_tile_start, (uint32_t*)nullptr, R.d_chunk_base, R.d_total + 1, 0u);
         hipLaunchKernelGGL(raster_tile_scan, dim3(1), dim3(1024), 0, stream, R.d_tile_count, R.d_tile_start, n_tiles, R.d_total);
-        uint32_t n_pairs = 0;
-        RASTER_HIP(hipMemcpyAsync(&n_pairs, R.d_total, 4, hipMemcpyDeviceToHost, stream));
-        RASTER_HIP(hipStreamSynchronize(stream));
-        if (n_pairs > R.pair_capacity) {
-            if (R.d_pairs) (void)hipFree(R.d_pairs);
-            R.d_pairs = nullptr; R.pair_capacity = 0;
-            const size_t cap = (size_t)n_pairs + n_pairs / 4 + 1024;
-            RASTER_HIP(hipMalloc((void**)&R.d_pairs, cap * 4));
-            R.pair_capacity = cap;
-        }
-        if (n_pairs > 0) {
-            RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_tiles + 1) * 4, stream));      // now the fill cursors
-            RASTER_HIP(hipMemsetAsync(R.d_tile_back, 0, (size_t)(n_tiles + 1) * 4, stream));
-            hipLaunchKernelGGL(raster_fill_small, per_tri, b256, 0, stream, R.d_bins, R.n_tris, tiles_x, R.d_tile_count, R.d_tile_back,
-                               R.d_tile_start, R.d_pairs);
-            hipLaunchKernelGGL((raster_bin_big<true>), dim3(kBigWaves / 4), b256, 0, stream, R.d_bins, tiles_x, R.d_tile_count, R.d_tile_back,
-                               R.d_tile_start, R.d_pairs, R.d_chunk_base, R.d_total + 1);
-        }
     }
     // A frame in page-locked memory (mrt_host_alloc) is written by the kernel itself, covered pixels only; any
     // other frame comes back through page-locked staging and its covered pixels are merged in on the host
@@ -560,11 +545,7 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
         }
         (void)hipGetLastError();
     }
-    hipLaunchKernelGGL(raster_tile, dim3(n_tiles), dim3(256), 0, stream, R.d_setup, R.d_tile_start, R.d_pairs, tiles_x, tx,
-                       fb_direct ? fb_direct : R.d_fb, fb_direct ? pitch_px : W, fb_direct ? 1 : 0,
-                       zbuf ? R.d_z : nullptr, tri_ids ? R.d_ids : nullptr, W, H);
-    RASTER_HIP(hipGetLastError());
-    const size_t need = npx * 4 + (tri_ids ? npx * 4 : 0) + (zbuf ? npx * 4 : 0);
+    const size_t need = npx * 4 + (tri_ids ? npx * 4 : 0) + (zbuf ? npx * 4 : 0) + 64;
     if (R.h_stage_bytes < need) {
         if (R.h_stage) (void)hipHostFree(R.h_stage);
         R.h_stage = nullptr; R.h_stage_bytes = 0;
@@ -573,13 +554,50 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
     }
     unsigned char* stage = static_cast<unsigned char*>(R.h_stage);
     uint32_t* h_fb = reinterpret_cast<uint32_t*>(stage);
-    unsigned char* next = stage + npx * 4;
-    if (!fb_direct) RASTER_HIP(hipMemcpyAsync(h_fb, R.d_fb, npx * 4, hipMemcpyDeviceToHost, stream));
-    if (tri_ids) { RASTER_HIP(hipMemcpyAsync(next, R.d_ids, npx * 4, hipMemcpyDeviceToHost, stream)); }
-    unsigned char* ids_stage = next;
-    if (tri_ids) next += npx * 4;
-    if (zbuf) RASTER_HIP(hipMemcpyAsync(next, R.d_z, npx * 4, hipMemcpyDeviceToHost, stream));
-    RASTER_HIP(hipStreamSynchronize(stream));      // also: h_mesh_tex may be rewritten by the next call only after its copy has been read
+    unsigned char* ids_stage = stage + npx * 4;
+    unsigned char* z_stage = ids_stage + (tri_ids ? npx * 4 : 0);
+    volatile uint32_t* h_pairs = reinterpret_cast<volatile uint32_t*>(z_stage + (zbuf ? npx * 4 : 0));   // the frame's pair count
+    auto grow_pairs = [&](uint32_t n_pairs) -> int {
+        if (n_pairs <= R.pair_capacity) return MRT_OK;
+        if (R.d_pairs) (void)hipFree(R.d_pairs);
+        R.d_pairs = nullptr; R.pair_capacity = 0;
+        const size_t cap = (size_t)n_pairs + n_pairs / 4 + 1024;
+        RASTER_HIP(hipMalloc((void**)&R.d_pairs, cap * 4));
+        R.pair_capacity = cap;
+        return MRT_OK;
+    };
+    // The pair buffer keeps the size an earlier frame needed and the frame is queued without waiting for this
+    // frame's count; only when there is no buffer yet, or when the count read back with the frame turns out
+    // larger than the buffer, the host waits, grows the buffer and queues the fill and tile passes (again).
+    *h_pairs = 0;
+    if (R.n_tris > 0 && R.pair_capacity == 0) {
+        RASTER_HIP(hipMemcpyAsync((void*)h_pairs, R.d_total, 4, hipMemcpyDeviceToHost, stream));
+        RASTER_HIP(hipStreamSynchronize(stream));
+        if (int rc = grow_pairs(*h_pairs)) return rc;
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const uint32_t capacity = (uint32_t)std::min<size_t>(R.pair_capacity, 0xffffffffu);
+        if (R.n_tris > 0 && capacity > 0) {
+            const dim3 per_tri((R.n_tris + 255) / 256), b256(256);
+            RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_tiles + 1) * 4, stream));      // now the fill cursors
+            RASTER_HIP(hipMemsetAsync(R.d_tile_back, 0, (size_t)(n_tiles + 1) * 4, stream));
+            hipLaunchKernelGGL(raster_fill_small, per_tri, b256, 0, stream, R.d_bins, R.n_tris, tiles_x, R.d_tile_count, R.d_tile_back,
+                               R.d_tile_start, R.d_pairs, capacity);
+            hipLaunchKernelGGL((raster_bin_big<true>), dim3(kBigWaves / 4), b256, 0, stream, R.d_bins, tiles_x, R.d_tile_count, R.d_tile_back,
+                               R.d_tile_start, R.d_pairs, R.d_chunk_base, R.d_total + 1, capacity);
+        }
+        hipLaunchKernelGGL(raster_tile, dim3(n_tiles), dim3(256), 0, stream, R.d_setup, R.d_tile_start, R.d_pairs, tiles_x, tx,
+                           fb_direct ? fb_direct : R.d_fb, fb_direct ? pitch_px : W, fb_direct ? 1 : 0,
+                           zbuf ? R.d_z : nullptr, tri_ids ? R.d_ids : nullptr, W, H, capacity);
+        RASTER_HIP(hipGetLastError());
+        if (!fb_direct) RASTER_HIP(hipMemcpyAsync(h_fb, R.d_fb, npx * 4, hipMemcpyDeviceToHost, stream));
+        if (tri_ids) RASTER_HIP(hipMemcpyAsync(ids_stage, R.d_ids, npx * 4, hipMemcpyDeviceToHost, stream));
+        if (zbuf) RASTER_HIP(hipMemcpyAsync(z_stage, R.d_z, npx * 4, hipMemcpyDeviceToHost, stream));
+        if (R.n_tris > 0) RASTER_HIP(hipMemcpyAsync((void*)h_pairs, R.d_total, 4, hipMemcpyDeviceToHost, stream));
+        RASTER_HIP(hipStreamSynchronize(stream));      // also: h_mesh_tex may be rewritten by the next call only after its copy has been read
+        if (*h_pairs <= R.pair_capacity) break;
+        if (int rc = grow_pairs(*h_pairs)) return rc;  // this frame needs a longer pair list than any before it: once more
+    }
     if (!fb_direct)
         for (int y = 0; y < H; ++y) {
             const uint32_t* src = h_fb + (size_t)y * W;
@@ -587,7 +605,7 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
             for (int x = 0; x < W; ++x) dst[x] = src[x] == kUncovered ? dst[x] : src[x];
         }
     if (tri_ids) memcpy(tri_ids, ids_stage, npx * 4);
-    if (zbuf) memcpy(zbuf, next, npx * 4);
+    if (zbuf) memcpy(zbuf, z_stage, npx * 4);
     return MRT_OK;
 }
 

@@ -88,3 +88,31 @@ def test_raster_random_poses(maze_scene, maze_oracle):
         _check(rts[(W, H)], maze_oracle, oracle_lib.lookat(tuple(pos), tuple(target)), W, H)
     for rt in rts.values():
         rt.close()
+
+
+def test_raster_pair_buffer_grows_between_frames():
+    """The list of (tile, triangle) pairs keeps the size an earlier frame needed and the frame is queued without
+    waiting for its own count; a later frame that needs a longer list must be rendered again, not truncated.
+    First a view that sees little of the soup, then one that sees all of it, compared with a fresh context."""
+    from raytracing_amd import Camera
+    scene = scene_io.soup_scene(60000)
+    W, H = 1280, 720
+    away = Camera()
+    away.set_position((0.0, 0.0, -60.0))       # behind the soup, looking on along -z: nothing or very little in view
+    away.look_at((0.0, 0.0, -100.0))
+    edge = Camera()
+    edge.set_position((30.0, 1.0, -20.0))      # from the side: part of it
+    edge.look_at((0.0, 0.0, -25.0))
+    full = Camera()
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(scene)
+    got = [rt.raster(c) for c in (away, edge, full, edge, full)]
+    rt.close()
+    for i, c in enumerate((away, edge, full, edge, full)):
+        fresh = Raytracer(W, H, device=0)
+        fresh.build_bvh(scene)
+        want = fresh.raster(c)
+        fresh.close()
+        for a, b in zip(got[i], want):
+            assert np.array_equal(a, b), "frame %d differs from a fresh context's" % i
+    assert (got[2][2] >= 0).mean() > 0.9 and (got[0][2] >= 0).mean() < 0.5
