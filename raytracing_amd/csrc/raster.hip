@@ -176,9 +176,10 @@ __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* 
             }
         }
     }
+    // a culled triangle is in no tile's list, so nobody reads its record: only its bin record says so
+    if (T.n == 0) { bins[i] = make_uint2(0u, 0u); return; }
     out[i] = T;
     // binning, first pass: the triangle's tile range for the fill pass, and the tiles' triangle counts
-    if (T.n == 0) { bins[i] = make_uint2(0u, 0u); return; }
     const TileRange r = tile_range(T);
     bins[i] = pack_bin(r, is_near(T, near_thr));
     if (r.tw * r.th > kSmallTiles) { big[atomicAdd(big_count, 1u)] = i; return; }
