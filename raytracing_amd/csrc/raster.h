@@ -49,9 +49,8 @@ struct RasterState {
     uint2* d_bins = nullptr;          // per triangle: tile range, near / drawn flags (8 bytes; what the binning passes read)
     uint32_t* d_chunk_base = nullptr; // n_tris words: list of the triangles that overlap many tiles
     uint32_t* d_total = nullptr;     // [0] (tile, triangle) pairs this frame, [1] length of the big-triangle list
-    uint32_t* d_tile_count = nullptr; // per 32x32 tile: triangle count, then fill cursor
-    uint32_t* d_tile_start = nullptr; // per tile (+1): start of its list in d_pairs
-    uint32_t* d_tile_back = nullptr;  // per tile: how many entries have been filled in from the END of its list
+    uint32_t* d_tile_count = nullptr; // per (32x32 tile, depth class): triangle count, then fill cursor
+    uint32_t* d_tile_start = nullptr; // per (tile, depth class) (+1): start of its list segment in d_pairs
     uint32_t n_tile_slots = 0;
     uint32_t* d_pairs = nullptr;     // triangle indices, grouped by tile
     size_t pair_capacity = 0;

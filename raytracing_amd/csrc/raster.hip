@@ -65,24 +65,30 @@ __device__ __forceinline__ TileRange tile_range(const RasterTri& T) {
     r.tw = (T.x1 >> kTileShift) - r.tx0 + 1; r.th = (T.y1 >> kTileShift) - r.ty0 + 1;
     return r;
 }
-__device__ __forceinline__ bool is_near(const RasterTri& T, float near_thr) {
+// Depth class of a triangle for the order of the tile lists: view-space z at the middle of its bounding box,
+// kDepthClasses equal steps from the nearest to the farthest corner of the visible meshes (class 0 nearest).
+// Only the order in which a tile meets its triangles depends on it, never a pixel.
+constexpr int kDepthClasses = 8;
+__device__ __forceinline__ int depth_class(const RasterTri& T, float z_near, float z_scale) {
     const float cx = 0.5f * (float)(T.x0 + T.x1), cy = 0.5f * (float)(T.y0 + T.y1);
-    return T.zA * cx + T.zB * cy + T.zC < near_thr;
+    const float z = 1.0f / (T.zA * cx + T.zB * cy + T.zC);              // negative in front of the camera
+    const float c = (z_near - z) * z_scale;
+    return c >= 0.0f ? min((int)c, kDepthClasses - 1) : 0;              // a NaN goes to class 0
 }
 // What binning needs of a triangle, 8 bytes instead of the 164-byte set-up record:
-// lo = first tile column | first tile row << 12 | near << 24 | drawn << 25, hi = tile columns | tile rows << 12
-__device__ __forceinline__ uint2 pack_bin(const TileRange& r, bool near) {
-    return make_uint2((uint32_t)r.tx0 | ((uint32_t)r.ty0 << 12) | (near ? 1u << 24 : 0u) | (1u << 25), (uint32_t)r.tw | ((uint32_t)r.th << 12));
+// lo = first tile column | first tile row << 12 | depth class << 24 | drawn << 27, hi = tile columns | tile rows << 12
+__device__ __forceinline__ uint2 pack_bin(const TileRange& r, int cls) {
+    return make_uint2((uint32_t)r.tx0 | ((uint32_t)r.ty0 << 12) | ((uint32_t)cls << 24) | (1u << 27), (uint32_t)r.tw | ((uint32_t)r.th << 12));
 }
-__device__ __forceinline__ bool bin_drawn(uint2 b) { return (b.x >> 25) & 1u; }
-__device__ __forceinline__ bool bin_near(uint2 b) { return (b.x >> 24) & 1u; }
+__device__ __forceinline__ bool bin_drawn(uint2 b) { return (b.x >> 27) & 1u; }
+__device__ __forceinline__ uint32_t bin_class(uint2 b) { return (b.x >> 24) & 7u; }
 __device__ __forceinline__ TileRange bin_range(uint2 b) {
     return TileRange{(int)(b.x & 0xfffu), (int)((b.x >> 12) & 0xfffu), (int)(b.y & 0xfffu), (int)((b.y >> 12) & 0xfffu)};
 }
 
 __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* pos, const float* uv, const float* N, const int32_t* tri,
                                                      const int32_t* tri_mesh, const int32_t* mesh_tex, RasterTri* out, uint32_t n_tris, uint2* bins, int tiles_x,
-                                                     uint32_t* tile_count, uint32_t* big, uint32_t* big_count, float near_thr) {
+                                                     uint32_t* tile_count, uint32_t* big, uint32_t* big_count, float z_near, float z_scale) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_tris) return;
     RasterTri T;
@@ -181,10 +187,11 @@ __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* 
     out[i] = T;
     // binning, first pass: the triangle's tile range for the fill pass, and the tiles' triangle counts
     const TileRange r = tile_range(T);
-    bins[i] = pack_bin(r, is_near(T, near_thr));
+    const int cls = depth_class(T, z_near, z_scale);
+    bins[i] = pack_bin(r, cls);
     if (r.tw * r.th > kSmallTiles) { big[atomicAdd(big_count, 1u)] = i; return; }
     for (int j = 0; j < r.th; ++j)
-        for (int k = 0; k < r.tw; ++k) atomicAdd(&tile_count[(r.ty0 + j) * tiles_x + r.tx0 + k], 1u);
+        for (int k = 0; k < r.tw; ++k) atomicAdd(&tile_count[((r.ty0 + j) * tiles_x + r.tx0 + k) * kDepthClasses + cls], 1u);
 }
 
 // Is pixel (x, y) plotted by the reference's scan conversion of this polygon?  The row extent of
@@ -247,48 +254,48 @@ __device__ __forceinline__ void resolve_pixel(const RasterTri* setup, unsigned l
 // Binning in two passes.  Counting: raster_setup itself counts the triangles of every tile and lists the
 // big triangles, raster_bin_big<false> counts those.  Filling, after the scan has turned counts into list
 // starts: raster_fill_small and raster_bin_big<true> write the lists (cursor = running fill position per tile).
-// A tile's list is filled from both ends: triangles nearer than `near_thr` (1/z at the middle of their
-// bounding box; more negative = nearer) from the front, the others from the back.  The tile kernel
-// walks the list front to back, so the near ones lower the blocks' depth bounds before the far ones
-// are met, most of which are then skipped block by block.  The order changes no pixel.
+// A tile's list is kDepthClasses consecutive segments, nearest class first (counts, starts and fill cursors are
+// kept per (tile, class)).  The tile kernel walks the list front to back, so near triangles lower the blocks'
+// depth bounds before the far ones are met, most of which are then skipped.  The order changes no pixel.
 // `capacity`: entries the pair buffer holds.  It was sized from an earlier frame; a frame that needs more is
 // rendered again after the buffer has grown, so entries past the end are only kept from being written.
 template <bool FILL>
-__device__ __forceinline__ void bin_one(uint32_t t, uint32_t tile, bool front, uint32_t* tile_count, uint32_t* tile_back,
-                                        const uint32_t* tile_start, uint32_t* pairs, uint32_t capacity) {
-    if (!FILL) { atomicAdd(&tile_count[tile], 1u); return; }
-    const uint32_t at = front ? tile_start[tile] + atomicAdd(&tile_count[tile], 1u)
-                              : tile_start[tile + 1] - 1u - atomicAdd(&tile_back[tile], 1u);
-    if (at < capacity) pairs[at] = t;
+__device__ __forceinline__ void bin_one(uint32_t t, uint32_t slot, uint32_t* tile_count, const uint32_t* tile_start, uint32_t* pairs,
+                                        uint32_t capacity) {
+    const uint32_t k = atomicAdd(&tile_count[slot], 1u);
+    if (FILL) {
+        const uint32_t at = tile_start[slot] + k;
+        if (at < capacity) pairs[at] = t;
+    }
 }
 // second pass for the triangles that overlap few tiles: one thread per triangle writes it into its tiles' lists
 __global__ __launch_bounds__(256) void raster_fill_small(const uint2* bins, uint32_t n_tris, int tiles_x, uint32_t* tile_count,
-                                                          uint32_t* tile_back, const uint32_t* tile_start, uint32_t* pairs, uint32_t capacity) {
+                                                          const uint32_t* tile_start, uint32_t* pairs, uint32_t capacity) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tris) return;
     const uint2 b = bins[t];
     if (!bin_drawn(b)) return;
     const TileRange r = bin_range(b);
     if (r.tw * r.th > kSmallTiles) return;
-    const bool front = bin_near(b);
+    const uint32_t cls = bin_class(b);
     for (int j = 0; j < r.th; ++j)
         for (int i = 0; i < r.tw; ++i)
-            bin_one<true>(t, (uint32_t)((r.ty0 + j) * tiles_x + r.tx0 + i), front, tile_count, tile_back, tile_start, pairs, capacity);
+            bin_one<true>(t, (uint32_t)((r.ty0 + j) * tiles_x + r.tx0 + i) * kDepthClasses + cls, tile_count, tile_start, pairs, capacity);
 }
 // triangles that overlap many tiles, one wave each.  FILL = false: count; FILL = true: write the lists
 template <bool FILL>
-__global__ __launch_bounds__(256) void raster_bin_big(const uint2* bins, int tiles_x, uint32_t* tile_count, uint32_t* tile_back,
-                                                       const uint32_t* tile_start, uint32_t* pairs, const uint32_t* big,
-                                                       const uint32_t* big_count, uint32_t capacity) {
+__global__ __launch_bounds__(256) void raster_bin_big(const uint2* bins, int tiles_x, uint32_t* tile_count, const uint32_t* tile_start,
+                                                       uint32_t* pairs, const uint32_t* big, const uint32_t* big_count, uint32_t capacity) {
     const uint32_t n = *big_count;
     const int lane = threadIdx.x & 63;
     for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += kBigWaves) {
         const uint32_t t = big[i];
         const uint2 b = bins[t];
         const TileRange r = bin_range(b);
-        const bool front = FILL && bin_near(b);
+        const uint32_t cls = bin_class(b);
         for (int k = lane; k < r.tw * r.th; k += 64)
-            bin_one<FILL>(t, (uint32_t)((r.ty0 + k / r.tw) * tiles_x + r.tx0 + k % r.tw), front, tile_count, tile_back, tile_start, pairs, capacity);
+            bin_one<FILL>(t, (uint32_t)((r.ty0 + k / r.tw) * tiles_x + r.tx0 + k % r.tw) * kDepthClasses + cls, tile_count, tile_start, pairs,
+                          capacity);
     }
 }
 // exclusive scan of the tile counts by one workgroup; total[0] receives the number of (tile, triangle) pairs
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(256) void raster_tile(const RasterTri* setup, const
     __syncthreads();
     const int tile = blockIdx.x, px0 = (tile % tiles_x) << kTileShift, py0 = (tile / tiles_x) << kTileShift;
     const int lane = threadIdx.x & 63;
-    const uint32_t begin = tile_start[tile], end = min(tile_start[tile + 1], capacity);
+    const uint32_t begin = tile_start[tile * kDepthClasses], end = min(tile_start[(tile + 1) * kDepthClasses], capacity);
     for (uint32_t i = begin + (threadIdx.x >> 6); i < end; i += 4) {
         const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)pairs[i]);
         const RasterTri& T = setup[t];
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(256) void raster_tile(const RasterTri* setup, const
 
 void raster_release(RasterState& R) {
     for (void* p : {(void*)R.d_pos, (void*)R.d_uv, (void*)R.d_N, (void*)R.d_tri, (void*)R.d_tri_mesh, (void*)R.d_mesh_tex, (void*)R.d_setup, (void*)R.d_bins,
-                    (void*)R.d_pairs, (void*)R.d_chunk_base, (void*)R.d_total, (void*)R.d_tile_count, (void*)R.d_tile_start, (void*)R.d_tile_back,
+                    (void*)R.d_pairs, (void*)R.d_chunk_base, (void*)R.d_total, (void*)R.d_tile_count, (void*)R.d_tile_start,
                     (void*)R.d_fb, (void*)R.d_z, (void*)R.d_ids})
         if (p) (void)hipFree(p);
     if (R.h_stage) (void)hipHostFree(R.h_stage);
@@ -479,13 +486,12 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
     frustum_planes(W, H, frustum);
     // per-mesh frustum cull (rasterizer.cpp:92-98) and the "texture required" rule (:102)
     R.h_mesh_tex.assign(R.meshes.size(), -1);
-    double depth_sum = 0.0;
-    size_t depth_n = 0;
+    float z_hi = -1e30f, z_lo = 1e30f;          // view-space z range of the visible meshes' bounding boxes
     for (size_t m = 0; m < R.meshes.size(); ++m) {
         const RasterMeshHost& h = R.meshes[m];
         bool visible = h.tris > 0 && h.texture >= 0;
+        f3 c[8];
         if (visible) {
-            f3 c[8];
             for (int i = 0; i < 8; i++) {
                 const f4 v = mul(M, f4{h.bounds[i & 1].x, h.bounds[(i >> 1) & 1].y, h.bounds[i >> 2].z, 1});
                 c[i] = {v.x, v.y, v.z};
@@ -499,40 +505,38 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
         }
         if (visible) {
             R.h_mesh_tex[m] = h.texture;
-            const f4 mid = mul(M, f4{0.5f * (h.bounds[0].x + h.bounds[1].x), 0.5f * (h.bounds[0].y + h.bounds[1].y),
-                                     0.5f * (h.bounds[0].z + h.bounds[1].z), 1});
-            depth_sum += (double)mid.z * h.tris; depth_n += h.tris;
+            for (int i = 0; i < 8; i++) { z_hi = std::max(z_hi, c[i].z); z_lo = std::min(z_lo, c[i].z); }
         }
     }
-    // "near" for the fill order of the tile lists: in front of the triangle-weighted middle of the visible meshes
-    // (view space looks down -z; 1/z of a nearer point is more negative).  Only a heuristic for the order.
-    const double mid_z = depth_n > 0 ? depth_sum / (double)depth_n : 0.0;
-    const float near_thr = mid_z < -1e-6 ? (float)(1.0 / mid_z) : -INFINITY;
+    // depth classes for the order of the tile lists: equal steps of view-space z (negative in front of the camera)
+    // from the nearest to the farthest corner of the visible meshes; only a heuristic for the order
+    const float z_near = std::min(z_hi, -0.2f);                 // nothing nearer than the near plane is drawn
+    const float z_scale = z_lo < z_near ? (float)kDepthClasses / (z_near - z_lo) : 0.0f;
     RasterFrame F;
     memcpy(F.M, &M, 64);
     for (int p = 0; p < 2; ++p) { F.frustum[p][0] = frustum[p].x; F.frustum[p][1] = frustum[p].y; F.frustum[p][2] = frustum[p].z; F.frustum[p][3] = frustum[p].w; }
     F.W = W; F.H = H;
     const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile;
     const uint32_t n_tiles = (uint32_t)(tiles_x * tiles_y);
-    if (R.n_tile_slots < n_tiles + 1) {
-        for (void* p : {(void*)R.d_tile_count, (void*)R.d_tile_start, (void*)R.d_tile_back}) if (p) (void)hipFree(p);
-        R.d_tile_count = nullptr; R.d_tile_start = nullptr; R.d_tile_back = nullptr; R.n_tile_slots = 0;
-        RASTER_HIP(hipMalloc((void**)&R.d_tile_back, (size_t)(n_tiles + 1) * 4));
-        RASTER_HIP(hipMalloc((void**)&R.d_tile_count, (size_t)(n_tiles + 1) * 4));
-        RASTER_HIP(hipMalloc((void**)&R.d_tile_start, (size_t)(n_tiles + 1) * 4));
-        R.n_tile_slots = n_tiles + 1;
+    const uint32_t n_slots = n_tiles * (uint32_t)kDepthClasses;       // one list segment per (tile, depth class)
+    if (R.n_tile_slots < n_slots + 1) {
+        for (void* p : {(void*)R.d_tile_count, (void*)R.d_tile_start}) if (p) (void)hipFree(p);
+        R.d_tile_count = nullptr; R.d_tile_start = nullptr; R.n_tile_slots = 0;
+        RASTER_HIP(hipMalloc((void**)&R.d_tile_count, (size_t)(n_slots + 1) * 4));
+        RASTER_HIP(hipMalloc((void**)&R.d_tile_start, (size_t)(n_slots + 1) * 4));
+        R.n_tile_slots = n_slots + 1;
     }
-    RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_tiles + 1) * 4, stream));
-    RASTER_HIP(hipMemsetAsync(R.d_tile_start, 0, (size_t)(n_tiles + 1) * 4, stream));
+    RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_slots + 1) * 4, stream));
+    RASTER_HIP(hipMemsetAsync(R.d_tile_start, 0, (size_t)(n_slots + 1) * 4, stream));
     if (R.n_tris > 0) {
         const dim3 per_tri((R.n_tris + 255) / 256), b256(256);
         RASTER_HIP(hipMemcpyAsync(R.d_mesh_tex, R.h_mesh_tex.data(), R.h_mesh_tex.size() * 4, hipMemcpyHostToDevice, stream));
         RASTER_HIP(hipMemsetAsync(R.d_total, 0, 16, stream));          // [0] pairs, [1] big triangles
         hipLaunchKernelGGL(raster_setup, per_tri, b256, 0, stream, F, R.d_pos, R.d_uv, R.d_N, R.d_tri, R.d_tri_mesh, R.d_mesh_tex, R.d_setup, R.n_tris,
-                           R.d_bins, tiles_x, R.d_tile_count, R.d_chunk_base, R.d_total + 1, near_thr);
-        hipLaunchKernelGGL((raster_bin_big<false>), dim3(kBigWaves / 4), b256, 0, stream, R.d_bins, tiles_x, R.d_tile_count, R.d_tile_back,
-                           R.d_tile_start, (uint32_t*)nullptr, R.d_chunk_base, R.d_total + 1, 0u);
-        hipLaunchKernelGGL(raster_tile_scan, dim3(1), dim3(1024), 0, stream, R.d_tile_count, R.d_tile_start, n_tiles, R.d_total);
+                           R.d_bins, tiles_x, R.d_tile_count, R.d_chunk_base, R.d_total + 1, z_near, z_scale);
+        hipLaunchKernelGGL((raster_bin_big<false>), dim3(kBigWaves / 4), b256, 0, stream, R.d_bins, tiles_x, R.d_tile_count, R.d_tile_start,
+                           (uint32_t*)nullptr, R.d_chunk_base, R.d_total + 1, 0u);
+        hipLaunchKernelGGL(raster_tile_scan, dim3(1), dim3(1024), 0, stream, R.d_tile_count, R.d_tile_start, n_slots, R.d_total);
     }
     // A frame in page-locked memory (mrt_host_alloc) is written by the kernel itself, covered pixels only; any
     // other frame comes back through page-locked staging and its covered pixels are merged in on the host
@@ -580,12 +584,11 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
         const uint32_t capacity = (uint32_t)std::min<size_t>(R.pair_capacity, 0xffffffffu);
         if (R.n_tris > 0 && capacity > 0) {
             const dim3 per_tri((R.n_tris + 255) / 256), b256(256);
-            RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_tiles + 1) * 4, stream));      // now the fill cursors
-            RASTER_HIP(hipMemsetAsync(R.d_tile_back, 0, (size_t)(n_tiles + 1) * 4, stream));
-            hipLaunchKernelGGL(raster_fill_small, per_tri, b256, 0, stream, R.d_bins, R.n_tris, tiles_x, R.d_tile_count, R.d_tile_back,
-                               R.d_tile_start, R.d_pairs, capacity);
-            hipLaunchKernelGGL((raster_bin_big<true>), dim3(kBigWaves / 4), b256, 0, stream, R.d_bins, tiles_x, R.d_tile_count, R.d_tile_back,
-                               R.d_tile_start, R.d_pairs, R.d_chunk_base, R.d_total + 1, capacity);
+            RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_slots + 1) * 4, stream));      // now the fill cursors
+            hipLaunchKernelGGL(raster_fill_small, per_tri, b256, 0, stream, R.d_bins, R.n_tris, tiles_x, R.d_tile_count, R.d_tile_start,
+                               R.d_pairs, capacity);
+            hipLaunchKernelGGL((raster_bin_big<true>), dim3(kBigWaves / 4), b256, 0, stream, R.d_bins, tiles_x, R.d_tile_count, R.d_tile_start,
+                               R.d_pairs, R.d_chunk_base, R.d_total + 1, capacity);
         }
         hipLaunchKernelGGL(raster_tile, dim3(n_tiles), dim3(256), 0, stream, R.d_setup, R.d_tile_start, R.d_pairs, tiles_x, tx,
                            fb_direct ? fb_direct : R.d_fb, fb_direct ? pitch_px : W, fb_direct ? 1 : 0,
