@@ -90,10 +90,10 @@ __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* 
                                                      const int32_t* tri_mesh, const int32_t* mesh_tex, RasterTri* out, uint32_t n_tris, uint2* bins, int tiles_x,
                                                      uint32_t* tile_count, uint32_t* big, uint32_t* big_count, float z_near, float z_scale) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_tris) return;
+    const bool in_range = i < n_tris;
     RasterTri T;
     T.n = 0;
-    const int texture = mesh_tex[tri_mesh[i]];       // -1 when the mesh is culled or has no texture
+    const int texture = in_range ? mesh_tex[tri_mesh[i]] : -1;       // -1 when the mesh is culled or has no texture
     if (texture >= 0) {
         const int W = F.W, H = F.H;
         m4 M;
@@ -182,9 +182,21 @@ __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* 
             }
         }
     }
-    // a culled triangle is in no tile's list, so nobody reads its record: only its bin record says so
+    // The 164-byte records of a workgroup's 256 triangles are contiguous in memory: they go through LDS so that
+    // the workgroup writes them as whole cache lines instead of each thread scattering 41 words.  A culled
+    // triangle is in no tile's list, so nobody reads its record and it is not written: only its bin record says so.
+    constexpr uint32_t kWords = sizeof(RasterTri) / 4, kNWord = offsetof(RasterTri, n) / 4;
+    __shared__ uint32_t stage[256 * kWords];
+    reinterpret_cast<RasterTri*>(stage)[threadIdx.x] = T;
+    __syncthreads();
+    {
+        const uint32_t base = blockIdx.x * 256u, count = min(256u, n_tris - base);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(out + base);
+        for (uint32_t d = threadIdx.x; d < count * kWords; d += 256u)
+            if (stage[(d / kWords) * kWords + kNWord] != 0u) dst[d] = stage[d];
+    }
+    if (!in_range) return;
     if (T.n == 0) { bins[i] = make_uint2(0u, 0u); return; }
-    out[i] = T;
     // binning, first pass: the triangle's tile range for the fill pass, and the tiles' triangle counts
     const TileRange r = tile_range(T);
     const int cls = depth_class(T, z_near, z_scale);
@@ -298,23 +310,33 @@ __global__ __launch_bounds__(256) void raster_bin_big(const uint2* bins, int til
                           capacity);
     }
 }
-// exclusive scan of the tile counts by one workgroup; total[0] receives the number of (tile, triangle) pairs
-__global__ __launch_bounds__(1024) void raster_tile_scan(const uint32_t* tile_count, uint32_t* tile_start, uint32_t n_tiles, uint32_t* total) {
-    __shared__ uint32_t part[1024];
-    const uint32_t per = (n_tiles + 1023) / 1024, b = threadIdx.x * per, e = min(b + per, n_tiles);
-    uint32_t sum = 0;
-    for (uint32_t i = b; i < e; ++i) sum += tile_count[i];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) {
-        const uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+// exclusive scan of the list-segment counts by one workgroup, 8,192 consecutive entries at a time (eight per
+// thread); total[0] receives the number of (tile, triangle) pairs
+__global__ __launch_bounds__(1024) void raster_tile_scan(const uint32_t* tile_count, uint32_t* tile_start, uint32_t n, uint32_t* total) {
+    __shared__ uint32_t wave_sum[16];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 8192u) {
+        const uint32_t first = base + 8u * t;
+        uint32_t v[8], mine = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = first + k < n ? tile_count[first + k] : 0u; mine += v[k]; }
+        uint32_t incl = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+            if (lane >= (uint32_t)o) incl += up;
+        }
+        if (lane == 63u) wave_sum[wave] = incl;
         __syncthreads();
-        part[threadIdx.x] += v;
+        uint32_t before = 0, all = 0;
+        for (uint32_t w = 0; w < 16u; ++w) { const uint32_t x = wave_sum[w]; all += x; if (w < wave) before += x; }
+        uint32_t run = carry + before + incl - mine;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { if (first + k < n) tile_start[first + k] = run; run += v[k]; }
+        carry += all;
         __syncthreads();
     }
-    uint32_t run = part[threadIdx.x] - sum;
-    for (uint32_t i = b; i < e; ++i) { tile_start[i] = run; run += tile_count[i]; }
-    if (threadIdx.x == 1023) { tile_start[n_tiles] = part[1023]; total[0] = part[1023]; }
+    if (t == 0) { tile_start[n] = carry; total[0] = carry; }
 }
 
 __global__ __launch_bounds__(256) void raster_tile(const RasterTri* setup, const uint32_t* tile_start, const uint32_t* pairs, int tiles_x,
