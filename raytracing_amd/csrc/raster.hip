@@ -310,17 +310,29 @@ __global__ __launch_bounds__(256) void raster_bin_big(const uint2* bins, int til
                           capacity);
     }
 }
-// exclusive scan of the list-segment counts by one workgroup, 8,192 consecutive entries at a time (eight per
-// thread); total[0] receives the number of (tile, triangle) pairs
+// exclusive scan of the list-segment counts by one workgroup, 32,768 consecutive entries at a time (32 per
+// thread, all loads of a round in flight together: the counts were written by atomics and come from memory);
+// total[0] receives the number of (tile, triangle) pairs.  count and start are 16-byte aligned.
 __global__ __launch_bounds__(1024) void raster_tile_scan(const uint32_t* tile_count, uint32_t* tile_start, uint32_t n, uint32_t* total) {
+    constexpr int kPer = 32;
     __shared__ uint32_t wave_sum[16];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < n; base += 8192u) {
-        const uint32_t first = base + 8u * t;
-        uint32_t v[8], mine = 0;
+    for (uint32_t base = 0; base < n; base += 1024u * kPer) {
+        const uint32_t first = base + kPer * t;
+        uint32_t v[kPer], mine = 0;
+        if (first + kPer <= n) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { v[k] = first + k < n ? tile_count[first + k] : 0u; mine += v[k]; }
+            for (int k = 0; k < kPer; k += 4) {
+                const uint4 q = *reinterpret_cast<const uint4*>(tile_count + first + k);
+                v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) v[k] = first + k < n ? tile_count[first + k] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) mine += v[k];
         uint32_t incl = mine;
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
@@ -331,8 +343,17 @@ __global__ __launch_bounds__(1024) void raster_tile_scan(const uint32_t* tile_co
         uint32_t before = 0, all = 0;
         for (uint32_t w = 0; w < 16u; ++w) { const uint32_t x = wave_sum[w]; all += x; if (w < wave) before += x; }
         uint32_t run = carry + before + incl - mine;
+        if (first + kPer <= n) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { if (first + k < n) tile_start[first + k] = run; run += v[k]; }
+            for (int k = 0; k < kPer; k += 4) {
+                uint4 q;
+                q.x = run; run += v[k]; q.y = run; run += v[k + 1]; q.z = run; run += v[k + 2]; q.w = run; run += v[k + 3];
+                *reinterpret_cast<uint4*>(tile_start + first + k) = q;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) { if (first + k < n) tile_start[first + k] = run; run += v[k]; }
+        }
         carry += all;
         __syncthreads();
     }
