@@ -312,8 +312,9 @@ __global__ __launch_bounds__(256) void raster_bin_big(const uint2* bins, int til
 }
 // exclusive scan of the list-segment counts by one workgroup, 32,768 consecutive entries at a time (32 per
 // thread, all loads of a round in flight together: the counts were written by atomics and come from memory);
-// total[0] receives the number of (tile, triangle) pairs.  count and start are 16-byte aligned.
-__global__ __launch_bounds__(1024) void raster_tile_scan(const uint32_t* tile_count, uint32_t* tile_start, uint32_t n, uint32_t* total) {
+// total[0] receives the number of (tile, triangle) pairs.  count and start are 16-byte aligned.  The counts are
+// cleared as they are read: the fill pass uses the same array as its cursors.
+__global__ __launch_bounds__(1024) void raster_tile_scan(uint32_t* tile_count, uint32_t* tile_start, uint32_t n, uint32_t* total) {
     constexpr int kPer = 32;
     __shared__ uint32_t wave_sum[16];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -326,10 +327,14 @@ __global__ __launch_bounds__(1024) void raster_tile_scan(const uint32_t* tile_co
             for (int k = 0; k < kPer; k += 4) {
                 const uint4 q = *reinterpret_cast<const uint4*>(tile_count + first + k);
                 v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+                *reinterpret_cast<uint4*>(tile_count + first + k) = make_uint4(0u, 0u, 0u, 0u);
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < kPer; ++k) v[k] = first + k < n ? tile_count[first + k] : 0u;
+            for (int k = 0; k < kPer; ++k) {
+                v[k] = first + k < n ? tile_count[first + k] : 0u;
+                if (first + k < n) tile_count[first + k] = 0u;
+            }
         }
 #pragma unroll
         for (int k = 0; k < kPer; ++k) mine += v[k];
@@ -570,7 +575,6 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
         R.n_tile_slots = n_slots + 1;
     }
     RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_slots + 1) * 4, stream));
-    RASTER_HIP(hipMemsetAsync(R.d_tile_start, 0, (size_t)(n_slots + 1) * 4, stream));
     if (R.n_tris > 0) {
         const dim3 per_tri((R.n_tris + 255) / 256), b256(256);
         RASTER_HIP(hipMemcpyAsync(R.d_mesh_tex, R.h_mesh_tex.data(), R.h_mesh_tex.size() * 4, hipMemcpyHostToDevice, stream));
@@ -627,7 +631,8 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
         const uint32_t capacity = (uint32_t)std::min<size_t>(R.pair_capacity, 0xffffffffu);
         if (R.n_tris > 0 && capacity > 0) {
             const dim3 per_tri((R.n_tris + 255) / 256), b256(256);
-            RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_slots + 1) * 4, stream));      // now the fill cursors
+            // the fill cursors: left at zero by the scan; a second attempt finds them at the counts
+            if (attempt > 0) RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_slots + 1) * 4, stream));
             hipLaunchKernelGGL(raster_fill_small, per_tri, b256, 0, stream, R.d_bins, R.n_tris, tiles_x, R.d_tile_count, R.d_tile_start,
                                R.d_pairs, capacity);
             hipLaunchKernelGGL((raster_bin_big<true>), dim3(kBigWaves / 4), b256, 0, stream, R.d_bins, tiles_x, R.d_tile_count, R.d_tile_start,
