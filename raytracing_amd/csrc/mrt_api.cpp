@@ -503,10 +503,14 @@ int mrt_render(mrt_ctx* c, const float cam[16], uint32_t flags, uint32_t* fb, in
     if (hit_ids) MRT_HIP(c, hipMemcpyAsync(stage + fb_bytes, c->d_ids.p, id_bytes, hipMemcpyDeviceToHost, c->stream));
     MRT_HIP(c, hipMemcpyAsync(wd_stage, c->d_counters.p + 5, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     MRT_HIP(c, hipStreamSynchronize(c->stream));
-    if (direct) {}
-    else if (pitch_px == c->width) memcpy(fb, stage, fb_bytes);
-    else for (int y = 0; y < c->height; ++y) memcpy(fb + (size_t)y * pitch_px, stage + (size_t)y * c->width * 4, (size_t)c->width * 4);
-    if (hit_ids) memcpy(hit_ids, stage + fb_bytes, id_bytes);
+    // out of the staging buffer on a few threads: one thread copies a 1080p frame in about 0.4 ms
+    if (!direct)
+        parallel_for((size_t)c->height, [&](size_t y0, size_t y1) {
+            if (pitch_px == c->width) memcpy(fb + y0 * c->width, stage + y0 * c->width * 4, (y1 - y0) * c->width * 4);
+            else for (size_t y = y0; y < y1; ++y) memcpy(fb + y * pitch_px, stage + y * c->width * 4, (size_t)c->width * 4);
+        }, std::max<size_t>(1, ((size_t)1 << 19) / (size_t)c->width));
+    if (hit_ids)
+        parallel_for(id_bytes / 4, [&](size_t b, size_t e) { memcpy(hit_ids + b, stage + fb_bytes + 4 * b, (e - b) * 4); }, (size_t)1 << 19);
     const unsigned long long wd = *wd_stage;
     if (wd != 0) return fail(c, MRT_E_LIMIT, "a traversal loop exhausted its iteration budget (code " + std::to_string(wd) + ")");
     return MRT_OK;

@@ -24,6 +24,7 @@
 // functions are evaluated directly, so results differ only where a pixel centre lies within
 // rounding distance of an edge, a depth tie or a texel border.
 #include "raster.h"
+#include "host_parallel.h"
 
 #include <algorithm>
 
@@ -651,13 +652,15 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
         if (int rc = grow_pairs(*h_pairs)) return rc;  // this frame needs a longer pair list than any before it: once more
     }
     if (!fb_direct)
-        for (int y = 0; y < H; ++y) {
-            const uint32_t* src = h_fb + (size_t)y * W;
-            uint32_t* dst = fb + (size_t)y * pitch_px;
-            for (int x = 0; x < W; ++x) dst[x] = src[x] == kUncovered ? dst[x] : src[x];
-        }
-    if (tri_ids) memcpy(tri_ids, ids_stage, npx * 4);
-    if (zbuf) memcpy(zbuf, z_stage, npx * 4);
+        parallel_for((size_t)H, [&](size_t y0, size_t y1) {
+            for (size_t y = y0; y < y1; ++y) {
+                const uint32_t* src = h_fb + y * W;
+                uint32_t* dst = fb + y * pitch_px;
+                for (int x = 0; x < W; ++x) dst[x] = src[x] == kUncovered ? dst[x] : src[x];
+            }
+        }, 64);
+    if (tri_ids) parallel_for(npx, [&](size_t b, size_t e) { memcpy(tri_ids + b, ids_stage + 4 * b, (e - b) * 4); }, (size_t)1 << 18);
+    if (zbuf) parallel_for(npx, [&](size_t b, size_t e) { memcpy(zbuf + b, z_stage + 4 * b, (e - b) * 4); }, (size_t)1 << 18);
     return MRT_OK;
 }
 
