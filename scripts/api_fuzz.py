@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Random sequences of C-ABI calls on a few contexts (uploads of different scenes, both shaders, bands, interleaved
+shares, queued frames, rasterizer frames, light changes, context destruction) with every frame checked against a
+frame rendered by a fresh context for the same scene, lights and camera.  Looks for state that leaks from one call
+into the next (tile order, cost history, pair buffer, queued-frame slots).  usage: api_fuzz.py [ops] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    n_ops = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    import torch
+    from raytracing_amd import Camera, Raytracer, scene_io, MODE_PACKET, MODE_RECURSIVE
+    from raytracing_amd.binding import HostFrame
+    W, H = 320, 200
+    maze = scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "maze.mrts"))
+    scenes = {"maze": maze, "soup3k": scene_io.soup_scene(3000, seed=7), "soup40k": scene_io.soup_scene(40000, seed=9)}
+    for m in scenes["soup3k"]["meshes"]:
+        m["refl"], m["refr"], m["rindex"] = 0.4, 0.3, 1.5
+
+    def fresh(scene_name, lights):
+        rt = Raytracer(W, H, device=0)
+        rt.build_bvh(scenes[scene_name])
+        rt.set_lights(lights)
+        return rt
+
+    def rand_cam():
+        c = Camera()
+        if rng.random() < 0.8:
+            c.set_position(tuple(rng.uniform(-12, 12, 3) * np.array([1, 0.3, 1]) + np.array([0, 1, 0])))
+            c.look_at(tuple(rng.uniform(-8, 8, 3) * np.array([1, 0.2, 1]) + np.array([0, 0, -15 if rng.random() < 0.5 else 0])))
+        return c
+
+    def rand_lights():
+        n = int(rng.integers(0, 3))
+        L = np.zeros((n, 7), np.float32)
+        for i in range(n):
+            L[i, :3] = rng.uniform(-6, 6, 3) + np.array([0, 5, 0])
+            L[i, 3:] = 1
+        return L
+
+    ctx = []          # [rt, scene name, lights]
+    refs = {}         # (scene name, lights bytes) -> fresh context for reference frames
+    checked = 0
+
+    def reference(scene_name, lights):
+        key = (scene_name, lights.tobytes())
+        if key not in refs:
+            if len(refs) > 6:
+                refs.pop(next(iter(refs))).close()
+            refs[key] = fresh(scene_name, lights)
+        return refs[key]
+
+    for op in range(n_ops):
+        if not ctx or (len(ctx) < 3 and rng.random() < 0.15):
+            name = str(rng.choice(list(scenes)))
+            lights = rand_lights()
+            ctx.append([fresh(name, lights), name, lights])
+            continue
+        k = int(rng.integers(0, len(ctx)))
+        rt, name, lights = ctx[k]
+        what = rng.random()
+        cam = rand_cam()
+        mode = MODE_RECURSIVE if rng.random() < 0.6 else MODE_PACKET
+        ref = reference(name, lights)
+        if what < 0.08:
+            rt.close()
+            ctx.pop(k)
+        elif what < 0.16:
+            name = str(rng.choice(list(scenes)))
+            rt.build_bvh(scenes[name])
+            ctx[k][1] = name
+        elif what < 0.24:
+            lights = rand_lights()
+            rt.set_lights(lights)
+            ctx[k][2] = lights
+        elif what < 0.50:
+            fb, ids = rt.render(cam, mode=mode)
+            fb2, ids2 = ref.render(cam, mode=mode)
+            assert np.array_equal(fb, fb2) and np.array_equal(ids, ids2), "op %d: render differs" % op
+            assert rt.ray_counts() == ref.ray_counts(), "op %d: ray counters differ" % op
+            checked += 1
+        elif what < 0.62:
+            y0 = 8 * int(rng.integers(0, H // 8))
+            y1 = 8 * int(rng.integers(y0 // 8 + 1, H // 8 + 1))
+            d = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+            rt.render_device(cam, d.data_ptr(), W, mode=mode, rows=(y0, y1), stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            fb2, _ = ref.render(cam, mode=mode)
+            assert np.array_equal(d.cpu().numpy().view(np.uint32)[y0:y1], fb2[y0:y1]), "op %d: band differs" % op
+            checked += 1
+        elif what < 0.72:
+            n_parts = int(rng.integers(2, 5))
+            d = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+            for p in rng.permutation(n_parts):
+                rt.render_device_part(cam, d.data_ptr(), W, int(p), n_parts, int(rng.integers(1, 3)) if False else 1, mode=mode,
+                                      stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            fb2, _ = ref.render(cam, mode=mode)
+            assert np.array_equal(d.cpu().numpy().view(np.uint32), fb2), "op %d: interleaved shares differ" % op
+            checked += 1
+        elif what < 0.86:
+            n = int(rng.integers(1, 5))
+            cams = [rand_cam() for _ in range(n)]
+            frames = [HostFrame(H, W) for _ in range(n)]
+            tickets = [rt.submit(c, f.array, mode=mode) for c, f in zip(cams, frames)]
+            for t, c, f in zip(tickets, cams, frames):
+                rt.wait(t)
+                assert np.array_equal(f.array, ref.render(c, mode=mode)[0]), "op %d: queued frame differs" % op
+                checked += 1
+            for f in frames:
+                f.close()
+        else:
+            a = rt.raster(cam)
+            b = ref.raster(cam)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), "op %d: rasterizer frame differs" % op
+            checked += 1
+    for c in ctx:
+        c[0].close()
+    for r in refs.values():
+        r.close()
+    print("api_fuzz: %d operations, %d frames compared with fresh contexts, all identical" % (n_ops, checked))
+
+
+if __name__ == "__main__":
+    main()

@@ -538,3 +538,15 @@ def test_random_pose_campaign():
     # and 25 random triangle soups with random reflecting / refracting materials and 0-3 lights
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "parity_fuzz.py"), "--soups", "25", "9"], capture_output=True, text=True)
     assert r.returncode == 0 and "hit ids identical" in r.stdout, r.stdout[-500:] + r.stderr[-500:]
+
+
+def test_api_sequence_fuzz():
+    """scripts/api_fuzz.py: random sequences of calls on up to three contexts (scene uploads, light changes, both
+    shaders, bands, interleaved shares, queued frames, rasterizer frames, destruction); every frame must equal the
+    frame a fresh context renders, so no state (tile order, cost history, pair buffer, queue slots) leaks between calls."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "api_fuzz.py"), "250", "11"], capture_output=True, text=True)
+    assert r.returncode == 0 and "all identical" in r.stdout, r.stdout[-500:] + r.stderr[-800:]
