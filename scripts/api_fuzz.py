@@ -45,6 +45,7 @@ def main():
             L[i, 3:] = 1
         return L
 
+    side_stream = torch.cuda.Stream()
     ctx = []          # [rt, scene name, lights]
     refs = {}         # (scene name, lights bytes) -> fresh context for reference frames
     checked = 0
@@ -81,8 +82,9 @@ def main():
             rt.set_lights(lights)
             ctx[k][2] = lights
         elif what < 0.50:
-            fb, ids = rt.render(cam, mode=mode)
-            fb2, ids2 = ref.render(cam, mode=mode)
+            g = 2 if rng.random() < 0.25 else 1
+            fb, ids = rt.render(cam, mode=mode, spp_grid=g)
+            fb2, ids2 = ref.render(cam, mode=mode, spp_grid=g)
             assert np.array_equal(fb, fb2) and np.array_equal(ids, ids2), "op %d: render differs" % op
             assert rt.ray_counts() == ref.ray_counts(), "op %d: ray counters differ" % op
             checked += 1
@@ -90,7 +92,9 @@ def main():
             y0 = 8 * int(rng.integers(0, H // 8))
             y1 = 8 * int(rng.integers(y0 // 8 + 1, H // 8 + 1))
             d = torch.zeros((H, W), dtype=torch.int32, device="cuda")
-            rt.render_device(cam, d.data_ptr(), W, mode=mode, rows=(y0, y1), stream=torch.cuda.current_stream().cuda_stream)
+            st = side_stream if rng.random() < 0.5 else torch.cuda.current_stream()      # launches of one context on two streams
+            st.wait_stream(torch.cuda.current_stream())
+            rt.render_device(cam, d.data_ptr(), W, mode=mode, rows=(y0, y1), stream=st.cuda_stream)
             torch.cuda.synchronize()
             fb2, _ = ref.render(cam, mode=mode)
             assert np.array_equal(d.cpu().numpy().view(np.uint32)[y0:y1], fb2[y0:y1]), "op %d: band differs" % op
