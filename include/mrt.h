@@ -42,6 +42,9 @@ extern "C" {
 #define MRT_MODE_RECURSIVE  1u        /* per-pixel GetColorFromSphere: reflection/refraction (raytracer.cpp:465-490, 575-664) */
 #define MRT_MODE_MASK       0xffu
 #define MRT_SPP_GRID(g)     (((uint32_t)(g) & 0xffu) << 8)   /* g in {1,2,4,8}: g*g samples per pixel */
+#define MRT_FLAG_FRAME_ORDER   (1u << 16)  /* hand tiles out in frame order, like the counter of threads.cpp:165, instead of
+                                              starting with the tiles that were expensive in the previous frame (same pixels) */
+#define MRT_FLAG_NO_RAY_COUNTS (1u << 17)  /* do not accumulate the counters mrt_get_ray_counts reads */
 
 typedef struct mrt_ctx mrt_ctx;
 
@@ -53,7 +56,9 @@ typedef struct mrt_mesh {
     const float*   tri_normal;  /* tris x 3, unit face normals (scenedata.cpp:251-256) */
     const int32_t* tri;         /* tris x 3 vertex indices */
     int32_t verts, tris;
-    int32_t texture_id;         /* index into the textures array, -1 = none (not traceable) */
+    int32_t texture_id;         /* index into the textures array.  Every mesh that has triangles must carry a texture
+                                   (Triangle::GetColor reads it unconditionally, raytracer.cpp:362-377): mrt_scene_upload
+                                   fails with MRT_E_ARG on -1 or an index outside the array */
     float   refl, refr, rindex; /* Object::m_Refl / m_Refr / m_RIndex (raytracer.h:76-78) */
 } mrt_mesh;
 

@@ -119,8 +119,12 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
-def flags(mode=MODE_PACKET, spp_grid=1):
-    return (mode & 0xFF) | ((spp_grid & 0xFF) << 8)
+FLAG_FRAME_ORDER = 1 << 16       # MRT_FLAG_FRAME_ORDER
+FLAG_NO_RAY_COUNTS = 1 << 17     # MRT_FLAG_NO_RAY_COUNTS
+
+
+def flags(mode=MODE_PACKET, spp_grid=1, extra=0):
+    return (mode & 0xFF) | ((spp_grid & 0xFF) << 8) | extra
 
 
 def _pack_scene(scene):
@@ -217,21 +221,21 @@ class Raytracer:
         a = np.ascontiguousarray(lights, np.float32).reshape(-1, 7)
         self._check(self.L.mrt_set_lights(self.h, _p(a), len(a)), "mrt_set_lights")
 
-    def render(self, cam, mode=MODE_PACKET, spp_grid=1, want_ids=True, fb=None):
+    def render(self, cam, mode=MODE_PACKET, spp_grid=1, want_ids=True, fb=None, extra_flags=0):
         """Raytracer::Render(camera) into a host framebuffer; returns (fb, hit_ids)."""
         cam = np.ascontiguousarray(getattr(cam, "transform", cam), np.float32).reshape(16)
         if fb is None:
             fb = np.zeros((self.height, self.width), np.uint32)
         g = max(1, spp_grid)
         ids = np.full((self.height * g, self.width * g), -2, np.int32) if want_ids else None
-        self._check(self.L.mrt_render(self.h, _p(cam), flags(mode, spp_grid), _p(fb), fb.strides[0] // 4, _p(ids)), "mrt_render")
+        self._check(self.L.mrt_render(self.h, _p(cam), flags(mode, spp_grid, extra_flags), _p(fb), fb.strides[0] // 4, _p(ids)), "mrt_render")
         return fb, ids
 
-    def render_device(self, cam, fb_ptr, pitch, mode=MODE_PACKET, spp_grid=1, rows=None, ids_ptr=None, stream=None):
+    def render_device(self, cam, fb_ptr, pitch, mode=MODE_PACKET, spp_grid=1, rows=None, ids_ptr=None, stream=None, extra_flags=0):
         """Asynchronous launch into device memory (raw pointers, e.g. torch.Tensor.data_ptr())."""
         cam = np.ascontiguousarray(getattr(cam, "transform", cam), np.float32).reshape(16)
         y0, y1 = rows if rows else (0, self.height)
-        self._check(self.L.mrt_render_device(self.h, _p(cam), flags(mode, spp_grid), y0, y1, C.c_void_p(fb_ptr), pitch,
+        self._check(self.L.mrt_render_device(self.h, _p(cam), flags(mode, spp_grid, extra_flags), y0, y1, C.c_void_p(fb_ptr), pitch,
                                              C.c_void_p(ids_ptr) if ids_ptr else None,
                                              C.c_void_p(stream) if stream else None), "mrt_render_device")
 

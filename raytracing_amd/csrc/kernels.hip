@@ -721,7 +721,7 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
     const f3 D = normalize(planepos - O);
 
     uint32_t n_shadow = 0, n_secondary = 0;
-    Watch wd{64 * (4 * S.n_node_slots + S.n_tris + 64), F.counters ? F.counters + 5 : nullptr};
+    Watch wd{watch_budget(S.n_node_slots, S.n_tris), F.counters ? F.counters + 5 : nullptr};
     Hit h;
     h.tri = -1; h.u = 0; h.v = 0;
     f4 color;
@@ -916,7 +916,8 @@ hipError_t launch_order_tiles(const uint32_t* cost, uint32_t* packed, uint32_t* 
 // Operator-level kernels on caller-supplied rays
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void trace_packets_kernel(SceneDev S, int n_packets, const float* O, const float* D,
-                                                           const float* rD, float* t, int32_t* tri, float* u, float* v) {
+                                                           const float* rD, float* t, int32_t* tri, float* u, float* v,
+                                                           unsigned long long* flag) {
     const int p = blockIdx.x, lane = threadIdx.x;
     if (p >= n_packets) return;
     const size_t r = (size_t)p * 64 + lane;
@@ -926,14 +927,14 @@ __global__ __launch_bounds__(64) void trace_packets_kernel(SceneDev S, int n_pac
     float tt = t[r];
     Hit h;
     h.tri = -1; h.u = 0; h.v = 0;
-    Watch wd{64 * (4 * S.n_node_slots + S.n_tris + 64), nullptr};
+    Watch wd{watch_budget(S.n_node_slots, S.n_tris), flag};
     traverse_packet(global_scene(S), S.n_tris, o, d, rd, tt, h, lane, wd);
     t[r] = tt; tri[r] = h.tri; u[r] = h.u; v[r] = h.v;
 }
 
 template <int SD>
 __global__ __launch_bounds__(64) void trace_rays_kernel(SceneDev S, int n_rays, const float* O, const float* D,
-                                                        float* t, int32_t* tri, float* u, float* v) {
+                                                        float* t, int32_t* tri, float* u, float* v, unsigned long long* flag) {
     __shared__ uint32_t lds_stack[SD * 64];
     const int lane = threadIdx.x;
     const size_t r = (size_t)blockIdx.x * 64 + lane;
@@ -943,7 +944,7 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(SceneDev S, int n_rays, 
     float tt = t[r];
     Hit h;
     h.u = 0; h.v = 0;
-    Watch wd{64 * (4 * S.n_node_slots + S.n_tris + 64), nullptr};
+    Watch wd{watch_budget(S.n_node_slots, S.n_tris), flag};
     traverse_nearest(global_scene(S), S.n_tris, S.coords_ok != 0, o, d, tt, h, (MRT_LDS uint32_t*)lds_stack + lane, wd);
     t[r] = tt; tri[r] = h.tri; u[r] = h.u; v[r] = h.v;
 }
@@ -969,7 +970,7 @@ static hipError_t launch_global_mode(const SceneDev& S, const FrameDev& F, hipSt
 }
 
 template <int MODE>
-static hipError_t launch_resident_mode(const SceneDev& S, const FrameDev& F, int n_cus, hipStream_t stream) {
+static hipError_t launch_resident_mode(const SceneDev& S, const FrameDev& F, int n_cus, int threads, hipStream_t stream) {
     const size_t lds = resident_lds_bytes(S.n_node_slots, S.n_tris, F.stack_entries);
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -981,8 +982,7 @@ static hipError_t launch_resident_mode(const SceneDev& S, const FrameDev& F, int
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) lds_limit_raised[dev] = true;
     }
-    int threads = kResidentThreads;
-    if (const char* e = getenv("MRT_RESIDENT_THREADS")) threads = std::max(64, std::min(kResidentThreads, atoi(e) / 64 * 64));   // tuning aid
+    threads = std::max(64, std::min(kResidentThreads, threads / 64 * 64));
     const int waves = threads / 64;
     const int blocks = std::max(1, std::min(n_cus, (F.n_tiles + waves - 1) / waves));
     hipLaunchKernelGGL((render_tiles_resident<MODE>), dim3((unsigned)blocks), dim3((unsigned)threads), lds, stream, S, F);
@@ -990,26 +990,28 @@ static hipError_t launch_resident_mode(const SceneDev& S, const FrameDev& F, int
 }
 
 // resident: use the LDS-resident persistent kernel (the caller has checked that the scene fits)
-hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool resident, int n_cus, hipStream_t stream) {
+// resident_threads: workgroup size of that kernel (kResidentThreads unless a diagnostic build says otherwise)
+hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool resident, int n_cus, int resident_threads, hipStream_t stream) {
     if (F.n_tiles <= 0) return hipSuccess;
-    if (resident) return mode == 0 ? launch_resident_mode<0>(S, F, n_cus, stream) : launch_resident_mode<1>(S, F, n_cus, stream);
+    if (resident) return mode == 0 ? launch_resident_mode<0>(S, F, n_cus, resident_threads, stream) : launch_resident_mode<1>(S, F, n_cus, resident_threads, stream);
     return mode == 0 ? launch_global_mode<0>(S, F, stream) : launch_global_mode<1>(S, F, stream);
 }
 
+// flag: one device word, zero on entry; a traversal that exhausts its loop budget leaves a code in it
 hipError_t launch_trace_packets(const SceneDev& S, int n_packets, const float* O, const float* D, const float* rD,
-                                float* t, int32_t* tri, float* u, float* v, hipStream_t stream) {
+                                float* t, int32_t* tri, float* u, float* v, unsigned long long* flag, hipStream_t stream) {
     if (n_packets <= 0) return hipSuccess;
-    hipLaunchKernelGGL(trace_packets_kernel, dim3((unsigned)n_packets), dim3(64), 0, stream, S, n_packets, O, D, rD, t, tri, u, v);
+    hipLaunchKernelGGL(trace_packets_kernel, dim3((unsigned)n_packets), dim3(64), 0, stream, S, n_packets, O, D, rD, t, tri, u, v, flag);
     return hipGetLastError();
 }
 
 hipError_t launch_trace_rays(const SceneDev& S, int n_rays, int stack_entries, const float* O, const float* D,
-                             float* t, int32_t* tri, float* u, float* v, hipStream_t stream) {
+                             float* t, int32_t* tri, float* u, float* v, unsigned long long* flag, hipStream_t stream) {
     if (n_rays <= 0) return hipSuccess;
     const dim3 grid((unsigned)((n_rays + 63) / 64)), block(64);
-    if (stack_entries <= 16) hipLaunchKernelGGL((trace_rays_kernel<16>), grid, block, 0, stream, S, n_rays, O, D, t, tri, u, v);
-    else if (stack_entries <= 32) hipLaunchKernelGGL((trace_rays_kernel<32>), grid, block, 0, stream, S, n_rays, O, D, t, tri, u, v);
-    else hipLaunchKernelGGL((trace_rays_kernel<kStackDepth>), grid, block, 0, stream, S, n_rays, O, D, t, tri, u, v);
+    if (stack_entries <= 16) hipLaunchKernelGGL((trace_rays_kernel<16>), grid, block, 0, stream, S, n_rays, O, D, t, tri, u, v, flag);
+    else if (stack_entries <= 32) hipLaunchKernelGGL((trace_rays_kernel<32>), grid, block, 0, stream, S, n_rays, O, D, t, tri, u, v, flag);
+    else hipLaunchKernelGGL((trace_rays_kernel<kStackDepth>), grid, block, 0, stream, S, n_rays, O, D, t, tri, u, v, flag);
     return hipGetLastError();
 }
 

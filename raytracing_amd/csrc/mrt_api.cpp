@@ -20,19 +20,27 @@
 #include "raster.h"
 
 namespace mrt {
-hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool resident, int n_cus, hipStream_t stream);
+hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool resident, int n_cus, int resident_threads, hipStream_t stream);
 hipError_t launch_order_tiles(const uint32_t* cost, uint32_t* packed, uint32_t* hist, uint32_t* order, int n, hipStream_t stream);
 size_t resident_lds_bytes(int n_node_slots, int n_tris, int stack_entries);
 hipError_t launch_trace_packets(const SceneDev& S, int n_packets, const float* O, const float* D, const float* rD,
-                                float* t, int32_t* tri, float* u, float* v, hipStream_t stream);
+                                float* t, int32_t* tri, float* u, float* v, unsigned long long* flag, hipStream_t stream);
 hipError_t launch_trace_rays(const SceneDev& S, int n_rays, int stack_entries, const float* O, const float* D,
-                             float* t, int32_t* tri, float* u, float* v, hipStream_t stream);
+                             float* t, int32_t* tri, float* u, float* v, unsigned long long* flag, hipStream_t stream);
 }  // namespace mrt
 
 using namespace mrt;
 
 namespace {
 thread_local std::string g_create_error;
+
+// Tuning aids read from the environment exist only in the diagnostic build (make diag): the release
+// library's behaviour depends on its arguments alone.
+#ifdef MRT_DEBUG_API
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+int env_int(const char*, int dflt) { return dflt; }
+#endif
 
 template <typename T>
 struct DevBuf {
@@ -80,9 +88,15 @@ struct mrt_ctx {
     // cost_shape identifies the launch they belong to (0: none)
     DevBuf<uint32_t> d_tile_cost, d_tile_packed, d_tile_order;
     unsigned long long cost_shape = 0;
+    // last_stream is only ever COMPARED with the stream of the next launch (it may be a caller's stream that no
+    // longer exists); everything that has to wait for the last launch waits on last_done.
     hipStream_t last_stream = nullptr;
     hipEvent_t last_done = nullptr;   // recorded after every frame launch: the context's counters and queues are shared,
     bool launched = false;            // so a launch on another stream first waits for the previous one
+    // ray arrays of the operator-level entry points, kept between calls (grown on demand)
+    DevBuf<float> d_rayO, d_rayD, d_rayR, d_rayT, d_rayU, d_rayV;
+    DevBuf<int32_t> d_rayTri;
+    DevBuf<unsigned long long> d_rayFlag;
     // page-locked staging for the synchronous entry point: device -> pinned at PCIe rate, then a host copy
     void* h_stage = nullptr;
     size_t h_stage_bytes = 0;
@@ -144,6 +158,7 @@ void fill_view(FrameDev& F, const float cam16[16], int w, int h) {
 int parse_flags(mrt_ctx* c, uint32_t flags, int& mode, int& g) {
     mode = (int)(flags & MRT_MODE_MASK);
     g = (int)((flags >> 8) & 0xffu);
+    if (flags & ~(MRT_MODE_MASK | 0xff00u | MRT_FLAG_FRAME_ORDER | MRT_FLAG_NO_RAY_COUNTS)) return fail(c, MRT_E_ARG, "unknown render flag");
     if (g == 0) g = 1;
     if (mode != (int)MRT_MODE_PACKET && mode != (int)MRT_MODE_RECURSIVE) return fail(c, MRT_E_ARG, "unknown render mode");
     if (g != 1 && g != 2 && g != 4 && g != 8) return fail(c, MRT_E_ARG, "supersampling grid must be 1, 2, 4 or 8");
@@ -187,15 +202,15 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
     F.hit_ids = ids_dev;
     F.counters = c->d_counters.p;
     F.stack_entries = c->stack_entries;
-    F.stats = getenv("MRT_NO_STATS") ? 0 : 1;
+    F.stats = (flags & MRT_FLAG_NO_RAY_COUNTS) ? 0 : 1;
     if (c->launched && stream != c->last_stream) MRT_HIP(c, hipStreamWaitEvent(stream, c->last_done, 0));
     MRT_HIP(c, hipMemsetAsync(c->d_counters.p, 0, kCounterSlots * sizeof(unsigned long long), stream));
     // The LDS-resident kernel pays off for the recursive shader, whose per-lane traversal reads a
     // different node or triangle in every lane.  The packet path reads wave-uniform data (scalar
     // loads through the scalar cache) and runs faster with one wave per tile at 8 waves per SIMD.
     bool resident = c->resident && mode == (int)MRT_MODE_RECURSIVE;
-    if (const char* e = getenv("MRT_RESIDENT_PACKET")) resident = c->resident && atoi(e) != 0;   // tuning aid
-    if (resident && F.n_tiles < (1 << 24) && !getenv("MRT_NO_TILE_ORDER")) {
+    if (env_int("MRT_RESIDENT_PACKET", 0)) resident = c->resident;
+    if (resident && F.n_tiles < (1 << 24) && !(flags & MRT_FLAG_FRAME_ORDER)) {
         // Launches of the same shape follow each other in a frame loop with a slowly moving camera:
         // start the tiles that were expensive last time first.
         const unsigned long long shape = ((unsigned long long)F.n_tiles << 24) ^ ((unsigned long long)F.tile_y0 << 12) ^
@@ -212,7 +227,7 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
         F.tile_cost = c->d_tile_cost.p;
         c->cost_shape = shape;
     }
-    MRT_HIP(c, launch_render(c->scene, F, mode, resident, c->n_cus, stream));
+    MRT_HIP(c, launch_render(c->scene, F, mode, resident, c->n_cus, env_int("MRT_RESIDENT_THREADS", kResidentThreads), stream));
     MRT_HIP(c, hipEventRecord(c->last_done, stream));
     c->last_stream = stream;
     c->launched = true;
@@ -264,7 +279,9 @@ void mrt_destroy(mrt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
-    if (c->last_stream) { (void)hipStreamSynchronize(c->last_stream); }
+    if (c->launched) { (void)hipEventSynchronize(c->last_done); }     // the last frame may be on a caller's stream
+    c->d_rayO.release(); c->d_rayD.release(); c->d_rayR.release(); c->d_rayT.release(); c->d_rayU.release(); c->d_rayV.release();
+    c->d_rayTri.release(); c->d_rayFlag.release();
     c->d_nodes.release(); c->d_triA.release(); c->d_triB.release(); c->d_triC.release(); c->d_attr.release(); c->d_lights.release();
     c->d_tex.release(); c->d_texels.release(); c->d_pal.release();
     c->d_fb.release(); c->d_ids.release(); c->d_counters.release();
@@ -319,7 +336,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     MRT_HIP(c, hipSetDevice(c->device));
     std::string err;
     c->has_scene = false;
-    const bool timing = getenv("MRT_TIMING") != nullptr;           // tuning aid: stage times of the upload on stderr
+    const bool timing = env_int("MRT_TIMING", 0) != 0;             // stage times of the upload on stderr
     auto t_prev = std::chrono::steady_clock::now();
     auto stage = [&](const char* what) {
         if (!timing) return;
@@ -407,7 +424,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     // LDS residency: nodes + triangles + 16 per-lane stacks must fit one CU's LDS, node indices 16 bits
     c->resident = B.n_tris > 0 && slots < 65536 &&
                   resident_lds_bytes((int)slots, (int)B.n_tris, c->stack_entries) + 256 <= (size_t)kLdsBudget;
-    if (const char* e = getenv("MRT_RESIDENT")) c->resident = c->resident && atoi(e) != 0;   // tuning aid: 0 forces the global-memory kernel
+    c->resident = c->resident && env_int("MRT_RESIDENT", 1) != 0;      // 0 forces the global-memory kernel
     c->has_scene = true;
     c->cost_shape = 0;          // tile costs of the previous scene say nothing about this one
     return MRT_OK;
@@ -466,6 +483,7 @@ int mrt_part_rows(int height, int part, int n_parts, int block_tile_rows) {
 int mrt_render(mrt_ctx* c, const float cam[16], uint32_t flags, uint32_t* fb, int pitch_px, int32_t* hit_ids) {
     if (!c) return MRT_E_ARG;
     if (!fb) return fail(c, MRT_E_ARG, "null framebuffer");
+    if (pitch_px < c->width) return fail(c, MRT_E_ARG, "pitch smaller than width");
     int mode, g;
     if (int rc = parse_flags(c, flags, mode, g)) return rc;
     MRT_HIP(c, hipSetDevice(c->device));
@@ -481,7 +499,7 @@ int mrt_render(mrt_ctx* c, const float cam[16], uint32_t flags, uint32_t* fb, in
         hipPointerAttribute_t at;
         void* dp = nullptr;
         if (hipPointerGetAttributes(&at, fb) == hipSuccess && at.type == hipMemoryTypeHost &&
-            hipHostGetDevicePointer(&dp, fb, 0) == hipSuccess && dp && !getenv("MRT_NO_DIRECT_HOST")) {
+            hipHostGetDevicePointer(&dp, fb, 0) == hipSuccess && dp && !env_int("MRT_NO_DIRECT_HOST", 0)) {
             direct = true;
             fb_target = static_cast<uint32_t*>(dp);
             fb_pitch = pitch_px;
@@ -567,7 +585,7 @@ int mrt_render_wait(mrt_ctx* c, int ticket) {
 int mrt_get_ray_counts(mrt_ctx* c, uint64_t out[4]) {
     if (!c || !out) return MRT_E_ARG;
     MRT_HIP(c, hipSetDevice(c->device));
-    MRT_HIP(c, hipStreamSynchronize(c->last_stream));
+    if (c->launched) MRT_HIP(c, hipEventSynchronize(c->last_done));
     std::vector<unsigned long long> tmp(kCounterSlots);
     MRT_HIP(c, hipMemcpy(tmp.data(), c->d_counters.p, kCounterSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; ++i) out[i] = 0;
@@ -583,7 +601,7 @@ int mrt_get_ray_counts(mrt_ctx* c, uint64_t out[4]) {
 extern "C" int mrt_debug_loop_counts(mrt_ctx* c, uint64_t* out) {
     if (!c || !out) return MRT_E_ARG;
     MRT_HIP(c, hipSetDevice(c->device));
-    MRT_HIP(c, hipStreamSynchronize(c->last_stream));
+    if (c->launched) MRT_HIP(c, hipEventSynchronize(c->last_done));
     MRT_HIP(c, hipMemcpy(out, c->d_counters.p + kProfBase, 2 * kProfSites * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return MRT_OK;
 }
@@ -593,12 +611,45 @@ extern "C" int mrt_debug_loop_counts(mrt_ctx* c, uint64_t* out) {
 extern "C" int mrt_debug_tile_costs(mrt_ctx* c, uint32_t* out, int capacity) {
     if (!c || !out) return MRT_E_ARG;
     MRT_HIP(c, hipSetDevice(c->device));
-    MRT_HIP(c, hipStreamSynchronize(c->last_stream));
+    if (c->launched) MRT_HIP(c, hipEventSynchronize(c->last_done));
     const int n = (int)std::min<size_t>(c->d_tile_cost.n, (size_t)std::max(capacity, 0));
     if (n > 0) MRT_HIP(c, hipMemcpy(out, c->d_tile_cost.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return n;
 }
 #endif
+
+// Shared body of the two operator-level entry points: ray arrays up, one launch, results down.  rD == nullptr
+// selects the single-ray operator.  The device arrays stay with the context and grow on demand.
+static int trace_common(mrt_ctx* c, const char* what, size_t n, int n_packets, const float* O, const float* D, const float* rD,
+                        float* t, int32_t* tri, float* u, float* v) {
+    MRT_HIP(c, hipSetDevice(c->device));
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; return e == hipSuccess; };
+    unsigned long long flag = 0;
+    if (ok(c->d_rayO.ensure(3 * n)) && ok(c->d_rayD.ensure(3 * n)) && (!rD || ok(c->d_rayR.ensure(3 * n))) && ok(c->d_rayT.ensure(n)) &&
+        ok(c->d_rayU.ensure(n)) && ok(c->d_rayV.ensure(n)) && ok(c->d_rayTri.ensure(n)) && ok(c->d_rayFlag.ensure(1)) &&
+        ok(hipMemsetAsync(c->d_rayFlag.p, 0, sizeof(unsigned long long), c->stream)) &&
+        ok(hipMemcpyAsync(c->d_rayO.p, O, 12 * n, hipMemcpyHostToDevice, c->stream)) &&
+        ok(hipMemcpyAsync(c->d_rayD.p, D, 12 * n, hipMemcpyHostToDevice, c->stream)) &&
+        (!rD || ok(hipMemcpyAsync(c->d_rayR.p, rD, 12 * n, hipMemcpyHostToDevice, c->stream))) &&
+        ok(hipMemcpyAsync(c->d_rayT.p, t, 4 * n, hipMemcpyHostToDevice, c->stream)) &&
+        ok(rD ? launch_trace_packets(c->scene, n_packets, c->d_rayO.p, c->d_rayD.p, c->d_rayR.p, c->d_rayT.p, c->d_rayTri.p, c->d_rayU.p,
+                                     c->d_rayV.p, c->d_rayFlag.p, c->stream)
+              : launch_trace_rays(c->scene, (int)n, c->stack_entries, c->d_rayO.p, c->d_rayD.p, c->d_rayT.p, c->d_rayTri.p, c->d_rayU.p,
+                                  c->d_rayV.p, c->d_rayFlag.p, c->stream)) &&
+        ok(hipMemcpyAsync(t, c->d_rayT.p, 4 * n, hipMemcpyDeviceToHost, c->stream)) &&
+        ok(hipMemcpyAsync(tri, c->d_rayTri.p, 4 * n, hipMemcpyDeviceToHost, c->stream)) &&
+        ok(hipMemcpyAsync(u, c->d_rayU.p, 4 * n, hipMemcpyDeviceToHost, c->stream)) &&
+        ok(hipMemcpyAsync(v, c->d_rayV.p, 4 * n, hipMemcpyDeviceToHost, c->stream)) &&
+        ok(hipMemcpyAsync(&flag, c->d_rayFlag.p, sizeof(flag), hipMemcpyDeviceToHost, c->stream)))
+        ok(hipStreamSynchronize(c->stream));
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(c->stream);
+        return fail(c, MRT_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    }
+    if (flag != 0) return fail(c, MRT_E_LIMIT, "a traversal loop exhausted its iteration budget (code " + std::to_string(flag) + ")");
+    return MRT_OK;
+}
 
 int mrt_trace_packets(mrt_ctx* c, int n_packets, const float* O, const float* D, const float* rD, float* t,
                       int32_t* tri, float* u, float* v) {
@@ -606,29 +657,7 @@ int mrt_trace_packets(mrt_ctx* c, int n_packets, const float* O, const float* D,
     if (n_packets < 0 || !O || !D || !rD || !t || !tri || !u || !v) return fail(c, MRT_E_ARG, "null ray array");
     if (!c->has_scene) return fail(c, MRT_E_STATE, "mrt_scene_upload has not been called");
     if (n_packets == 0) return MRT_OK;
-    MRT_HIP(c, hipSetDevice(c->device));
-    const size_t n = (size_t)n_packets * 64;
-    DevBuf<float> dO, dD, dR, dt, du, dv;
-    DevBuf<int32_t> dtri;
-    int rc = MRT_OK;
-    hipError_t e = hipSuccess;
-    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; return e == hipSuccess; };
-    if (ok(dO.ensure(3 * n)) && ok(dD.ensure(3 * n)) && ok(dR.ensure(3 * n)) && ok(dt.ensure(n)) && ok(du.ensure(n)) &&
-        ok(dv.ensure(n)) && ok(dtri.ensure(n)) &&
-        ok(hipMemcpyAsync(dO.p, O, 12 * n, hipMemcpyHostToDevice, c->stream)) &&
-        ok(hipMemcpyAsync(dD.p, D, 12 * n, hipMemcpyHostToDevice, c->stream)) &&
-        ok(hipMemcpyAsync(dR.p, rD, 12 * n, hipMemcpyHostToDevice, c->stream)) &&
-        ok(hipMemcpyAsync(dt.p, t, 4 * n, hipMemcpyHostToDevice, c->stream)) &&
-        ok(launch_trace_packets(c->scene, n_packets, dO.p, dD.p, dR.p, dt.p, dtri.p, du.p, dv.p, c->stream)) &&
-        ok(hipMemcpyAsync(t, dt.p, 4 * n, hipMemcpyDeviceToHost, c->stream)) &&
-        ok(hipMemcpyAsync(tri, dtri.p, 4 * n, hipMemcpyDeviceToHost, c->stream)) &&
-        ok(hipMemcpyAsync(u, du.p, 4 * n, hipMemcpyDeviceToHost, c->stream)) &&
-        ok(hipMemcpyAsync(v, dv.p, 4 * n, hipMemcpyDeviceToHost, c->stream)))
-        ok(hipStreamSynchronize(c->stream));
-    if (e != hipSuccess) rc = fail(c, MRT_E_HIP, std::string("mrt_trace_packets: ") + hipGetErrorString(e));
-    (void)hipStreamSynchronize(c->stream);
-    dO.release(); dD.release(); dR.release(); dt.release(); du.release(); dv.release(); dtri.release();
-    return rc;
+    return trace_common(c, "mrt_trace_packets", (size_t)n_packets * 64, n_packets, O, D, rD, t, tri, u, v);
 }
 
 int mrt_trace_rays(mrt_ctx* c, int n_rays, const float* O, const float* D, float* t, int32_t* tri, float* u, float* v) {
@@ -636,28 +665,7 @@ int mrt_trace_rays(mrt_ctx* c, int n_rays, const float* O, const float* D, float
     if (n_rays < 0 || !O || !D || !t || !tri || !u || !v) return fail(c, MRT_E_ARG, "null ray array");
     if (!c->has_scene) return fail(c, MRT_E_STATE, "mrt_scene_upload has not been called");
     if (n_rays == 0) return MRT_OK;
-    MRT_HIP(c, hipSetDevice(c->device));
-    const size_t n = (size_t)n_rays;
-    DevBuf<float> dO, dD, dt, du, dv;
-    DevBuf<int32_t> dtri;
-    int rc = MRT_OK;
-    hipError_t e = hipSuccess;
-    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; return e == hipSuccess; };
-    if (ok(dO.ensure(3 * n)) && ok(dD.ensure(3 * n)) && ok(dt.ensure(n)) && ok(du.ensure(n)) && ok(dv.ensure(n)) &&
-        ok(dtri.ensure(n)) &&
-        ok(hipMemcpyAsync(dO.p, O, 12 * n, hipMemcpyHostToDevice, c->stream)) &&
-        ok(hipMemcpyAsync(dD.p, D, 12 * n, hipMemcpyHostToDevice, c->stream)) &&
-        ok(hipMemcpyAsync(dt.p, t, 4 * n, hipMemcpyHostToDevice, c->stream)) &&
-        ok(launch_trace_rays(c->scene, n_rays, c->stack_entries, dO.p, dD.p, dt.p, dtri.p, du.p, dv.p, c->stream)) &&
-        ok(hipMemcpyAsync(t, dt.p, 4 * n, hipMemcpyDeviceToHost, c->stream)) &&
-        ok(hipMemcpyAsync(tri, dtri.p, 4 * n, hipMemcpyDeviceToHost, c->stream)) &&
-        ok(hipMemcpyAsync(u, du.p, 4 * n, hipMemcpyDeviceToHost, c->stream)) &&
-        ok(hipMemcpyAsync(v, dv.p, 4 * n, hipMemcpyDeviceToHost, c->stream)))
-        ok(hipStreamSynchronize(c->stream));
-    if (e != hipSuccess) rc = fail(c, MRT_E_HIP, std::string("mrt_trace_rays: ") + hipGetErrorString(e));
-    (void)hipStreamSynchronize(c->stream);
-    dO.release(); dD.release(); dt.release(); du.release(); dv.release(); dtri.release();
-    return rc;
+    return trace_common(c, "mrt_trace_rays", (size_t)n_rays, 0, O, D, nullptr, t, tri, u, v);
 }
 
 int mrt_raster_render(mrt_ctx* c, const float cam[16], uint32_t* fb, int pitch_px, float* zbuf, int32_t* tri_ids) {

@@ -95,6 +95,14 @@ MRT_HD bool div_shortcut_coord_ok(float c) {
     return (c == 0.0f) || ((a >= 0x1p-27f) && (a <= 0x1p30f));
 }
 
+// Iteration budget of the outer traversal loops of one tile or one operator call: far above what a
+// correct traversal of a tree with this many node slots and triangles can need, computed in 64 bits
+// and saturated (the product passes 2^31 near 3.7 million triangles).
+MRT_HD int watch_budget(int n_node_slots, int n_tris) {
+    const long long b = 64ll * (4ll * (long long)n_node_slots + (long long)n_tris + 64ll);
+    return b > 0x7fffffffll ? 0x7fffffff : (int)b;
+}
+
 MRT_HD uint32_t f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 MRT_HD float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 

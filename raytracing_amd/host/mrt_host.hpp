@@ -151,6 +151,7 @@ private:
     void LoadMRTS(const std::string& path) {
         FILE* f = fopen(path.c_str(), "rb");
         if (!f) throw std::runtime_error("File not found: " + path);
+        struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};     // also when a resize below throws
         char magic[4];
         uint32_t head[3];
         bool ok = ReadAll(f, magic, 4) && !memcmp(magic, "MRTS", 4) && ReadAll(f, head, 12) && head[0] == 1;
@@ -158,7 +159,7 @@ private:
         for (uint32_t i = 0; ok && i < head[1]; ++i) {
             Texture t;
             int32_t wh[2];
-            ok = ReadAll(f, wh, 8) && wh[0] > 0 && wh[1] > 0;
+            ok = ReadAll(f, wh, 8) && wh[0] > 0 && wh[1] > 0 && (int64_t)wh[0] * wh[1] < (1ll << 30);
             if (!ok) break;
             t.width = wh[0]; t.height = wh[1];
             t.indices.resize((size_t)wh[0] * wh[1]); t.palettes.resize(32 * 256);
@@ -169,7 +170,8 @@ private:
             Mesh m;
             int32_t h3[3];
             float mat[3], b[6];
-            ok = ReadAll(f, h3, 12) && ReadAll(f, mat, 12) && ReadAll(f, b, 24) && h3[0] >= 0 && h3[1] >= 0;
+            ok = ReadAll(f, h3, 12) && ReadAll(f, mat, 12) && ReadAll(f, b, 24) && h3[0] >= 0 && h3[1] >= 0 &&
+                 h3[0] < (1 << 30) && h3[1] < (1 << 30);
             if (!ok) break;
             m.texture = h3[2] < 0 ? -1 : h3[2] + tex_base;
             m.refl = mat[0]; m.refr = mat[1]; m.rindex = mat[2];
@@ -179,7 +181,6 @@ private:
                  ReadAll(f, m.tri.data(), 4 * m.tri.size());
             meshList.push_back(std::move(m));
         }
-        fclose(f);
         if (!ok) throw std::runtime_error("malformed scene container: " + path);
     }
 
@@ -337,9 +338,12 @@ public:
     // Raytracer::BuildBVH(meshList) (raytracer.cpp:670-673)
     void BuildBVH(const Scene& scene) {
         std::vector<mrt_mesh> meshes;
-        for (const Mesh& m : scene.meshList)
-            meshes.push_back(mrt_mesh{&m.pos[0].x, &m.uv[0].x, &m.N[0].x, m.tri.data(), m.verts(), m.tris(), m.texture,
+        for (const Mesh& m : scene.meshList) {
+            if (m.tris() == 0) continue;       // a "usemtl" that no face follows leaves an empty mesh: nothing to trace
+            meshes.push_back(mrt_mesh{reinterpret_cast<const float*>(m.pos.data()), reinterpret_cast<const float*>(m.uv.data()),
+                                      reinterpret_cast<const float*>(m.N.data()), m.tri.data(), m.verts(), m.tris(), m.texture,
                                       m.refl, m.refr, m.rindex});
+        }
         std::vector<mrt_texture> textures;
         for (const Texture& t : scene.texList) textures.push_back(mrt_texture{t.indices.data(), t.palettes.data(), t.width, t.height});
         check(mrt_scene_upload(ctx_, meshes.data(), (int)meshes.size(), textures.data(), (int)textures.size()), "mrt_scene_upload");

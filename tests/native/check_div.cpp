@@ -53,6 +53,22 @@ int main(int argc, char** argv) {
         !mrt::div_shortcut_dir_ok(-0.5f) || !mrt::div_shortcut_coord_ok(0.0f) || !mrt::div_shortcut_coord_ok(-17.8125f) ||
         mrt::div_shortcut_coord_ok(1e-12f) || mrt::div_shortcut_coord_ok(4e9f) || mrt::div_shortcut_coord_ok(__builtin_nanf("")))
         ++bad;
+    // loop budget of the traversal kernels: 64-bit arithmetic, saturated -- positive and monotone up to the largest
+    // scene the upload accepts (2^26 node slots, 2^30 triangles); the 32-bit product wrapped near 3.7 M triangles
+    {
+        int prev = 0;
+        const long long tris[] = {0, 1, 2120, 1000000, 3700000, 4000000, 33554430, 1073741823};
+        for (long long n : tris) {
+            const long long slots = 2 * n + 3 > (1ll << 26) ? (1ll << 26) : 2 * n + 3;
+            const int b = mrt::watch_budget((int)slots, (int)n);
+            const long long exact = 64 * (4 * slots + n + 64);
+            if (b <= 0 || b < prev || (exact <= 0x7fffffffll ? b != (int)exact : b != 0x7fffffff)) {
+                printf("watch_budget(%lld, %lld) = %d\n", slots, n, b);
+                ++bad;
+            }
+            prev = b;
+        }
+    }
     printf("tested=%ld mismatches=%ld\n", tested, bad);
     return bad == 0 ? 0 : 1;
 }

@@ -438,20 +438,18 @@ def test_launches_on_two_streams_do_not_disturb_each_other(maze_scene):
 
 
 @pytest.mark.parametrize("W,H", [(1000, 600), (16, 8), (256, 8)])
-def test_tile_order_from_previous_frame_changes_nothing(maze_scene, monkeypatch, W, H):
+def test_tile_order_from_previous_frame_changes_nothing(maze_scene, W, H):
     """The persistent kernel starts the tiles that were expensive in the previous launch of the same
     shape first.  Pixels, hit IDs and ray counters must not depend on that order: frames of a
     context that has a history (same pose again, then another pose) equal the frames rendered with
-    the ordering switched off."""
+    the ordering switched off (MRT_FLAG_FRAME_ORDER)."""
     rt = Raytracer(W, H, device=0)
     rt.build_bvh(maze_scene)
     cams = [pose_cam(POSES[0]), pose_cam(POSES[2])]
-    monkeypatch.setenv("MRT_NO_TILE_ORDER", "1")
     base = []
     for cam in cams:
-        fb, ids = rt.render(cam, mode=MODE_RECURSIVE)
+        fb, ids = rt.render(cam, mode=MODE_RECURSIVE, extra_flags=binding.FLAG_FRAME_ORDER)
         base.append((fb.copy(), ids.copy(), rt.ray_counts()))
-    monkeypatch.delenv("MRT_NO_TILE_ORDER")
     for which in (0, 0, 0, 1, 1, 0):
         fb, ids = rt.render(cams[which], mode=MODE_RECURSIVE)
         assert np.array_equal(ids, base[which][1]) and np.array_equal(fb, base[which][0])
@@ -497,9 +495,18 @@ def test_error_paths(maze_scene):
         rt.render(oracle_lib.IDENTITY, spp_grid=3)
     with pytest.raises(MrtError, match="mode"):
         rt.render(oracle_lib.IDENTITY, mode=7)
-    bad = {"textures": maze_scene["textures"], "meshes": [dict(maze_scene["meshes"][0], texture=9)]}
-    with pytest.raises(MrtError, match="texture"):
-        rt.build_bvh(bad)
+    for tex in (9, -1):        # outside the texture array; none at all (the tracer needs one on every mesh)
+        bad = {"textures": maze_scene["textures"], "meshes": [dict(maze_scene["meshes"][0], texture=tex)]}
+        with pytest.raises(MrtError, match="texture"):
+            rt.build_bvh(bad)
+    rt.build_bvh(maze_scene)
+    with pytest.raises(MrtError, match="flag"):
+        rt.render(oracle_lib.IDENTITY, extra_flags=1 << 20)
+    # a pitch smaller than the width is refused before anything is launched or written, for pageable frames too
+    fb = np.zeros((64, 64), np.uint32)
+    rc = rt.L.mrt_render(rt.h, binding._p(oracle_lib.IDENTITY), 0, binding._p(fb), 32, None)
+    assert rc == -1 and b"pitch" in rt.L.mrt_last_error(rt.h) and not fb.any()
+    assert rt.L.mrt_render(rt.h, binding._p(oracle_lib.IDENTITY), 0, binding._p(fb), -64, None) == -1
     rt.close()
 
 
