@@ -19,7 +19,7 @@ MODE_RECURSIVE = 1
 
 SYMBOLS = ("mrt_create", "mrt_destroy", "mrt_last_error", "mrt_version", "mrt_scene_upload", "mrt_scene_upload_lbvh",
            "mrt_set_lights",
-           "mrt_bvh_build_host", "mrt_render", "mrt_host_alloc", "mrt_host_free", "mrt_render_submit", "mrt_render_wait", "mrt_render_device", "mrt_render_device_part", "mrt_part_rows",
+           "mrt_bvh_build_host", "mrt_render", "mrt_host_alloc", "mrt_host_free", "mrt_render_submit", "mrt_render_wait", "mrt_render_device", "mrt_render_device_noalloc", "mrt_render_device_part", "mrt_part_rows",
            "mrt_raster_render", "mrt_trace_packets",
            "mrt_trace_rays", "mrt_get_ray_counts", "mrt_camera_look_at")
 
@@ -77,6 +77,7 @@ def lib():
         L.mrt_bvh_build_host.argtypes = [C.POINTER(_Mesh), i32, vp, vp, vp, vp]
         L.mrt_render.argtypes = [vp, vp, C.c_uint32, vp, i32, vp]
         L.mrt_render_device.argtypes = [vp, vp, C.c_uint32, i32, i32, vp, i32, vp, vp]
+        L.mrt_render_device_noalloc.argtypes = [vp, vp, C.c_uint32, i32, i32, vp, i32, vp, vp]
         L.mrt_host_alloc.argtypes = [C.c_size_t]
         L.mrt_host_alloc.restype = vp
         L.mrt_host_free.argtypes = [vp]
@@ -238,6 +239,14 @@ class Raytracer:
         self._check(self.L.mrt_render_device(self.h, _p(cam), flags(mode, spp_grid, extra_flags), y0, y1, C.c_void_p(fb_ptr), pitch,
                                              C.c_void_p(ids_ptr) if ids_ptr else None,
                                              C.c_void_p(stream) if stream else None), "mrt_render_device")
+
+    def render_device_noalloc(self, cam, fb_ptr, pitch, mode=MODE_PACKET, spp_grid=1, rows=None, ids_ptr=None, stream=None, extra_flags=0):
+        """mrt_render_device_noalloc: the same launch with its scratch memory in a fixed array of the library."""
+        cam = np.ascontiguousarray(getattr(cam, "transform", cam), np.float32).reshape(16)
+        y0, y1 = rows if rows else (0, self.height)
+        self._check(self.L.mrt_render_device_noalloc(self.h, _p(cam), flags(mode, spp_grid, extra_flags), y0, y1, C.c_void_p(fb_ptr), pitch,
+                                                     C.c_void_p(ids_ptr) if ids_ptr else None,
+                                                     C.c_void_p(stream) if stream else None), "mrt_render_device_noalloc")
 
     def render_device_part(self, cam, fb_ptr, pitch, part, n_parts, block_tile_rows=1, compact=False, mode=MODE_PACKET,
                            spp_grid=1, ids_ptr=None, stream=None):

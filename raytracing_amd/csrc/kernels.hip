@@ -972,21 +972,19 @@ static hipError_t launch_global_mode(const SceneDev& S, const FrameDev& F, hipSt
 template <int MODE>
 static hipError_t launch_resident_mode(const SceneDev& S, const FrameDev& F, int n_cus, int threads, hipStream_t stream) {
     const size_t lds = resident_lds_bytes(S.n_node_slots, S.n_tris, F.stack_entries);
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    static bool lds_limit_raised[64] = {};          // per device, once: the attribute call is a driver round trip
-    if (dev < 0 || dev >= 64 || !lds_limit_raised[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_tiles_resident<MODE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
-        if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) lds_limit_raised[dev] = true;
-    }
     threads = std::max(64, std::min(kResidentThreads, threads / 64 * 64));
     const int waves = threads / 64;
     const int blocks = std::max(1, std::min(n_cus, (F.n_tiles + waves - 1) / waves));
     hipLaunchKernelGGL((render_tiles_resident<MODE>), dim3((unsigned)blocks), dim3((unsigned)threads), lds, stream, S, F);
     return hipGetLastError();
+}
+
+// Once per device, with that device current (mrt_create): lets the persistent kernels use a whole CU's LDS.
+// Done at set-up so that a frame launch is nothing but launches.
+hipError_t prepare_render_kernels() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_tiles_resident<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&render_tiles_resident<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
 }
 
 // resident: use the LDS-resident persistent kernel (the caller has checked that the scene fits)

@@ -21,6 +21,7 @@
 
 namespace mrt {
 hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool resident, int n_cus, int resident_threads, hipStream_t stream);
+hipError_t prepare_render_kernels();
 hipError_t launch_order_tiles(const uint32_t* cost, uint32_t* packed, uint32_t* hist, uint32_t* order, int n, hipStream_t stream);
 size_t resident_lds_bytes(int n_node_slots, int n_tris, int stack_entries);
 hipError_t launch_trace_packets(const SceneDev& S, int n_packets, const float* O, const float* D, const float* rD,
@@ -63,6 +64,43 @@ struct DevBuf {
 };
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// Scratch memory of mrt_render_device_noalloc: what mrt_render_device keeps in buffers it allocates
+// (the frame's counter block with the tile queues, and the three per-tile arrays of the tile
+// ordering) lives here in a fixed array of the code object, so that entry point never allocates.
+// `scratch` is a host-side stand-in for the symbol, not an address: host code only ever uses the
+// per-device address that hipGetSymbolAddress returned at mrt_create (scratch_of), and the kernels
+// receive that address as an argument, exactly as they receive the allocated buffers elsewhere.
+// Every GPU holds its own copy (about 3.2 MB) until the process ends; all contexts on a GPU share it.
+// ---------------------------------------------------------------------------------------------
+constexpr int kNoAllocMaxTiles = MRT_NOALLOC_MAX_TILES;
+constexpr size_t kScratchCounterBytes = (size_t)kCounterSlots * sizeof(unsigned long long);
+constexpr size_t kScratchBytes = kScratchCounterBytes + 3 * (size_t)kNoAllocMaxTiles * sizeof(uint32_t);
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};            // device address of `scratch` on each GPU, once known
+unsigned long long g_scratch_shape[kMaxDevices] = {};       // launch the tile costs in a GPU's scratch belong to (0: none)
+
+// With `device` current: the address of this GPU's copy of the scratch array (looked up once per device).
+hipError_t scratch_of(int device, unsigned char** out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+}  // namespace
+
 struct mrt_ctx {
     int width = 0, height = 0, device = 0;
     hipStream_t stream = nullptr;
@@ -74,6 +112,7 @@ struct mrt_ctx {
     DevBuf<float4> d_nodes, d_triA, d_triB, d_attr, d_lights;
     DevBuf<float2> d_triC;
     bool resident = false;      // scene small enough for the LDS-resident kernel
+    unsigned scene_serial = 0;  // counts scene uploads
     int n_cus = 256;
     DevBuf<int4> d_tex;
     DevBuf<uint8_t> d_texels;
@@ -93,6 +132,8 @@ struct mrt_ctx {
     hipStream_t last_stream = nullptr;
     hipEvent_t last_done = nullptr;   // recorded after every frame launch: the context's counters and queues are shared,
     bool launched = false;            // so a launch on another stream first waits for the previous one
+    unsigned long long* last_counters = nullptr;   // counter block the last launch used (the context's own or the GPU's scratch)
+    unsigned char* scratch_dev = nullptr;          // this GPU's copy of the scratch array (mrt_render_device_noalloc)
     // ray arrays of the operator-level entry points, kept between calls (grown on demand)
     DevBuf<float> d_rayO, d_rayD, d_rayR, d_rayT, d_rayU, d_rayV;
     DevBuf<int32_t> d_rayTri;
@@ -174,8 +215,18 @@ int part_tile_rows(int rows, int part, int n_parts, int block) {
 
 struct RowShare { int part = 0, n_parts = 1, block = 1, compact = 0; };
 
+// Device memory a frame launch needs beyond its inputs and outputs.  nullptr for the per-tile arrays: allocate
+// (or reuse) the context's own; otherwise they hold `capacity` tiles and nothing is allocated.
+struct FrameScratch {
+    unsigned long long* counters = nullptr;
+    uint32_t *tile_cost = nullptr, *tile_packed = nullptr, *tile_order = nullptr;
+    unsigned long long* shape = nullptr;      // where the identity of the launch that wrote tile_cost is kept
+    int capacity = 0;
+};
+
 int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, int y_end, uint32_t* fb_dev,
-                  int pitch_px, int32_t* ids_dev, hipStream_t stream, const RowShare* share = nullptr) {
+                  int pitch_px, int32_t* ids_dev, hipStream_t stream, const RowShare* share = nullptr,
+                  const FrameScratch* fixed = nullptr) {
     int mode, g;
     if (int rc = parse_flags(c, flags, mode, g)) return rc;
     if (!c->has_scene) return fail(c, MRT_E_STATE, "mrt_scene_upload has not been called");
@@ -200,11 +251,14 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
     F.pitch = pitch_px;
     F.fb = fb_dev;
     F.hit_ids = ids_dev;
-    F.counters = c->d_counters.p;
+    F.counters = fixed ? fixed->counters : c->d_counters.p;
     F.stack_entries = c->stack_entries;
+    if (fixed && F.n_tiles > fixed->capacity)
+        return fail(c, MRT_E_LIMIT, "mrt_render_device_noalloc: " + std::to_string(F.n_tiles) + " tiles in this launch, the fixed scratch array holds " +
+                                    std::to_string(fixed->capacity) + " (MRT_NOALLOC_MAX_TILES)");
     F.stats = (flags & MRT_FLAG_NO_RAY_COUNTS) ? 0 : 1;
     if (c->launched && stream != c->last_stream) MRT_HIP(c, hipStreamWaitEvent(stream, c->last_done, 0));
-    MRT_HIP(c, hipMemsetAsync(c->d_counters.p, 0, kCounterSlots * sizeof(unsigned long long), stream));
+    MRT_HIP(c, hipMemsetAsync(F.counters, 0, kCounterSlots * sizeof(unsigned long long), stream));
     // The LDS-resident kernel pays off for the recursive shader, whose per-lane traversal reads a
     // different node or triangle in every lane.  The packet path reads wave-uniform data (scalar
     // loads through the scalar cache) and runs faster with one wave per tile at 8 waves per SIMD.
@@ -216,21 +270,31 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
         const unsigned long long shape = ((unsigned long long)F.n_tiles << 24) ^ ((unsigned long long)F.tile_y0 << 12) ^
                                          ((unsigned long long)g << 8) ^ ((unsigned long long)F.part << 4) ^
                                          ((unsigned long long)F.n_parts << 16) ^ ((unsigned long long)F.part_block << 40) ^ ((unsigned long long)mode << 1) ^ 1ull;
-        MRT_HIP(c, c->d_tile_cost.ensure((size_t)F.n_tiles));
-        MRT_HIP(c, c->d_tile_packed.ensure((size_t)F.n_tiles));
-        MRT_HIP(c, c->d_tile_order.ensure((size_t)F.n_tiles));
-        if (c->cost_shape == shape) {
-            MRT_HIP(c, launch_order_tiles(c->d_tile_cost.p, c->d_tile_packed.p, reinterpret_cast<uint32_t*>(c->d_counters.p + kOrderHistBase),
-                                          c->d_tile_order.p, F.n_tiles, stream));
-            F.tile_order = c->d_tile_order.p;
+        uint32_t *cost, *packed, *order;
+        unsigned long long* last_shape;
+        unsigned long long key = shape;
+        if (fixed) {
+            cost = fixed->tile_cost; packed = fixed->tile_packed; order = fixed->tile_order; last_shape = fixed->shape;
+            key ^= (unsigned long long)(uintptr_t)c * 0x9e3779b97f4a7c15ull ^ ((unsigned long long)c->scene_serial << 52);   // the scratch is shared by every context on the GPU
+            key |= 1ull;
+        } else {
+            MRT_HIP(c, c->d_tile_cost.ensure((size_t)F.n_tiles));
+            MRT_HIP(c, c->d_tile_packed.ensure((size_t)F.n_tiles));
+            MRT_HIP(c, c->d_tile_order.ensure((size_t)F.n_tiles));
+            cost = c->d_tile_cost.p; packed = c->d_tile_packed.p; order = c->d_tile_order.p; last_shape = &c->cost_shape;
         }
-        F.tile_cost = c->d_tile_cost.p;
-        c->cost_shape = shape;
+        if (*last_shape == key) {
+            MRT_HIP(c, launch_order_tiles(cost, packed, reinterpret_cast<uint32_t*>(F.counters + kOrderHistBase), order, F.n_tiles, stream));
+            F.tile_order = order;
+        }
+        F.tile_cost = cost;
+        *last_shape = key;
     }
     MRT_HIP(c, launch_render(c->scene, F, mode, resident, c->n_cus, env_int("MRT_RESIDENT_THREADS", kResidentThreads), stream));
     MRT_HIP(c, hipEventRecord(c->last_done, stream));
     c->last_stream = stream;
     c->launched = true;
+    c->last_counters = F.counters;
     return MRT_OK;
 }
 
@@ -258,6 +322,8 @@ int mrt_create(int width, int height, int device, mrt_ctx** out) {
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->last_done, hipEventDisableTiming);
     if (e == hipSuccess) e = c->d_counters.ensure(kCounterSlots);
+    if (e == hipSuccess) e = prepare_render_kernels();          // per-device kernel attributes, so that no frame launch has to set them
+    if (e == hipSuccess) e = scratch_of(device, &c->scratch_dev);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess) c->n_cus = prop.multiProcessorCount;
@@ -427,6 +493,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     c->resident = c->resident && env_int("MRT_RESIDENT", 1) != 0;      // 0 forces the global-memory kernel
     c->has_scene = true;
     c->cost_shape = 0;          // tile costs of the previous scene say nothing about this one
+    ++c->scene_serial;
     return MRT_OK;
 }
 
@@ -454,6 +521,21 @@ int mrt_render_device(mrt_ctx* c, const float cam[16], uint32_t flags, int y_beg
     if (!c) return MRT_E_ARG;
     MRT_HIP(c, hipSetDevice(c->device));
     return render_common(c, cam, flags, y_begin, y_end, (uint32_t*)fb_dev, pitch_px, (int32_t*)hit_ids_dev, (hipStream_t)stream);
+}
+
+int mrt_render_device_noalloc(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, int y_end, void* fb_dev,
+                              int pitch_px, void* hit_ids_dev, void* stream) {
+    if (!c) return MRT_E_ARG;
+    MRT_HIP(c, hipSetDevice(c->device));
+    if (!c->scratch_dev) return fail(c, MRT_E_STATE, "no scratch array on this device");
+    FrameScratch fs;
+    fs.counters = reinterpret_cast<unsigned long long*>(c->scratch_dev);
+    fs.tile_cost = reinterpret_cast<uint32_t*>(c->scratch_dev + kScratchCounterBytes);
+    fs.tile_packed = fs.tile_cost + kNoAllocMaxTiles;
+    fs.tile_order = fs.tile_packed + kNoAllocMaxTiles;
+    fs.capacity = kNoAllocMaxTiles;
+    fs.shape = &g_scratch_shape[c->device];
+    return render_common(c, cam, flags, y_begin, y_end, (uint32_t*)fb_dev, pitch_px, (int32_t*)hit_ids_dev, (hipStream_t)stream, nullptr, &fs);
 }
 
 void* mrt_host_alloc(size_t bytes) {
@@ -587,7 +669,8 @@ int mrt_get_ray_counts(mrt_ctx* c, uint64_t out[4]) {
     MRT_HIP(c, hipSetDevice(c->device));
     if (c->launched) MRT_HIP(c, hipEventSynchronize(c->last_done));
     std::vector<unsigned long long> tmp(kCounterSlots);
-    MRT_HIP(c, hipMemcpy(tmp.data(), c->d_counters.p, kCounterSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    MRT_HIP(c, hipMemcpy(tmp.data(), c->last_counters ? c->last_counters : c->d_counters.p, kCounterSlots * sizeof(unsigned long long),
+                         hipMemcpyDeviceToHost));
     for (int i = 0; i < 4; ++i) out[i] = 0;
     for (int s = 0; s < kStatSlots; ++s)
         for (int i = 0; i < 4; ++i) out[i] += tmp[kStatBase + 16 * s + i];
