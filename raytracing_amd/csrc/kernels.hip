@@ -44,6 +44,10 @@ constexpr int kMaxReflPasses = 5, kMaxRefrPasses = 5;   // raytracer.cpp:9-10
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+#ifndef MRT_LEAF_CHUNK
+#define MRT_LEAF_CHUNK 16       // triangles of a leaf a lane tests before the wave looks at inner nodes again
+#endif
+
 struct Hit { int tri; float u, v; };
 
 // Loop budget shared by the outer traversal loops of one tile (work-list loops, the per-lane
@@ -57,6 +61,14 @@ struct Watch {
     unsigned long long* flag;
 #ifdef MRT_LOOP_COUNTS
     uint32_t wave_n[kProfSites] = {}, lane_n[kProfSites] = {};
+    unsigned long long phase_t0 = 0;
+    // shader clocks of a phase of the wave's work, added to site `site` as its wave count (lane count = calls)
+    __device__ __forceinline__ void phase_begin() { phase_t0 = __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void phase_end(int site) {
+        const unsigned long long dt = __builtin_readcyclecounter() - phase_t0;
+        const int me = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        if (me == 0) { wave_n[site] += (uint32_t)(dt >> 4); ++lane_n[site]; }
+    }
     // one tick per wave-level execution of a site (counted on the first active lane) and one per lane
     __device__ __forceinline__ void tick(int site) {
         const int me = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -64,8 +76,12 @@ struct Watch {
         ++lane_n[site];
     }
 #define MRT_TICK(wd, site) (wd).tick(site)
+#define MRT_PHASE_BEGIN(wd) (wd).phase_begin()
+#define MRT_PHASE_END(wd, site) (wd).phase_end(site)
 #else
 #define MRT_TICK(wd, site) ((void)0)
+#define MRT_PHASE_BEGIN(wd) ((void)0)
+#define MRT_PHASE_END(wd, site) ((void)0)
 #endif
     __device__ __forceinline__ bool expired(unsigned long long code) {
         if (--left >= 0) return false;
@@ -85,6 +101,8 @@ struct SceneGlobal {
     __device__ __forceinline__ v4f tri_a(uint32_t k) const { return triA[k]; }
     __device__ __forceinline__ v4f tri_b(uint32_t k) const { return triB[k]; }
     __device__ __forceinline__ v2f tri_c(uint32_t k) const { return triC[k]; }
+    __device__ __forceinline__ v2f tri_b_lo(uint32_t k) const { return reinterpret_cast<const v2f*>(triB)[2 * k]; }
+    __device__ __forceinline__ v2f tri_b_hi(uint32_t k) const { return reinterpret_cast<const v2f*>(triB)[2 * k + 1]; }
     __device__ __forceinline__ uint32_t node_first(uint32_t n) const { return __float_as_uint(reinterpret_cast<const float*>(nodes)[8 * n + 3]); }
     __device__ __forceinline__ uint32_t node_count(uint32_t n) const { return __float_as_uint(reinterpret_cast<const float*>(nodes)[8 * n + 7]); }
 };
@@ -95,6 +113,8 @@ struct SceneLds {
     __device__ __forceinline__ v4f tri_a(uint32_t k) const { return triA[k]; }
     __device__ __forceinline__ v4f tri_b(uint32_t k) const { return triB[k]; }
     __device__ __forceinline__ v2f tri_c(uint32_t k) const { return triC[k]; }
+    __device__ __forceinline__ v2f tri_b_lo(uint32_t k) const { return ((MRT_LDS const v2f*)triB)[2 * k]; }
+    __device__ __forceinline__ v2f tri_b_hi(uint32_t k) const { return ((MRT_LDS const v2f*)triB)[2 * k + 1]; }
     __device__ __forceinline__ uint32_t node_first(uint32_t n) const { return __float_as_uint(((MRT_LDS const float*)nodes)[8 * n + 3]); }
     __device__ __forceinline__ uint32_t node_count(uint32_t n) const { return __float_as_uint(((MRT_LDS const float*)nodes)[8 * n + 7]); }
 };
@@ -203,7 +223,7 @@ __device__ __forceinline__ bool slab_pair_shadow_interval(v4f l0, v4f l1, v4f r0
 // ---------------------------------------------------------------------------------------
 template <bool WAVE_REJECT>
 __device__ __forceinline__ void tri_test(v4f A, v4f B, v2f C, f3 O, f3 D, float& t, Hit& h, Watch& wd) {
-    const f3 p0 = {A.x, A.y, A.z}, e1 = {A.w, B.x, B.y}, e2 = {B.z, B.w, C.x};
+    const f3 e1 = {A.x, A.y, A.z}, e2 = {A.w, B.x, B.y}, p0 = {B.z, B.w, C.x};
     const f3 pvec = cross(D, e2);
     const float det = dot(e1, pvec);
     if (WAVE_REJECT) {
@@ -407,15 +427,24 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
             }
         }
         if (alive) {
-            for (uint32_t k = first; k < first + count; ++k) {
+            // A leaf of the reference's tree holds up to about a hundred triangles while most hold two or
+            // three.  The lanes walk their leaves MRT_LEAF_CHUNK triangles at a time: a lane whose leaf is
+            // longer keeps the rest for the next leaf phase, and the lanes that are done go on with inner nodes
+            // in between instead of waiting for the longest leaf of the wave.  Per lane the sequence of tests
+            // is unchanged.
+            const uint32_t n_now = count < (uint32_t)MRT_LEAF_CHUNK ? count : (uint32_t)MRT_LEAF_CHUNK;
+            for (uint32_t k = first; k < first + n_now; ++k) {
                 MRT_TICK(wd, 1);
                 tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
             }
-            if (sp == 0) alive = false;
-            else {
-                --sp;
-                const uint32_t n = stack[sp * 64];
-                first = sc.node_first(n); count = sc.node_count(n);
+            first += n_now; count -= n_now;
+            if (count == 0) {
+                if (sp == 0) alive = false;
+                else {
+                    --sp;
+                    const uint32_t n = stack[sp * 64];
+                    first = sc.node_first(n); count = sc.node_count(n);
+                }
             }
         }
     }
@@ -611,7 +640,9 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
         h.tri = -1; h.u = 0; h.v = 0;
         float t = tmax;
         bool isHit = false;
+        MRT_PHASE_BEGIN(wd);
         if (tracing) isHit = traverse_nearest(sc, S.n_tris, S.coords_ok != 0, O, D, t, h, stack, wd);
+        MRT_PHASE_END(wd, 16);
         if (tracing && first) { primary = h; first = false; }
         const bool shade = tracing && isHit;
         Surf s;
@@ -619,7 +650,9 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
         f3 hit = O;
         if (shade) { s = fetch_surface(S, h); hit = O + D * t; }
         f4 finalColor = {0, 0, 0, 0};
+        MRT_PHASE_BEGIN(wd);
         direct_light(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
+        MRT_PHASE_END(wd, 17);
         if (!tracing) continue;
         tracing = false;
         bool returning;
@@ -816,6 +849,10 @@ template <int MODE>
 #endif
 __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_tiles_resident(SceneDev S, FrameDev F) {
     extern __shared__ __align__(16) unsigned char smem[];
+#ifdef MRT_LOOP_COUNTS
+    const unsigned long long t_enter = __builtin_readcyclecounter();
+    unsigned long long t_tiles = 0;
+#endif
     const uint32_t n_node_v4 = 2u * (uint32_t)S.n_node_slots, n_tri = (uint32_t)S.n_tris;
     MRT_LDS v4f* l_nodes = (MRT_LDS v4f*)smem;
     MRT_LDS v4f* l_a = l_nodes + n_node_v4;
@@ -833,12 +870,19 @@ __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_t
     __syncthreads();
     const SceneLds sc{l_nodes, l_a, l_b, l_c};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef MRT_LOOP_COUNTS
+    const unsigned long long t_ready = __builtin_readcyclecounter();
+#endif
     MRT_LDS uint16_t* stack = l_stacks + (size_t)wave * F.stack_entries * 64 + lane;
     // Tile queue.  One shared counter would serialise every pull of every wave on one address
     // (tens of thousands of returning atomics per frame); instead the tiles are dealt round-robin
     // into kTileQueues queues, each with its own counter on its own cache line.  A workgroup
     // starts on queue (blockIdx % kTileQueues) and moves on to the next queue when one runs dry,
     // so all tiles are drawn exactly once whatever the placement of the workgroups.
+    // (Measured and dropped: pulling the next tile while the current one renders, which hides the pull's
+    // round trip to the L2 -- 8 % slower, because with the expensive tiles handed out first a tile reserved
+    // early waits behind an expensive one; and finding the next queue with tiles by reading all counters at
+    // once instead of one failed pull per dry queue -- 2 % slower.)
     const int n_queues = F.n_tiles < kTileQueues ? 1 : kTileQueues;
     int q = (int)(blockIdx.x % (unsigned)n_queues), dry = 0;
     for (int pulls = 0; pulls <= F.n_tiles + n_queues && dry < n_queues; ++pulls) {   // bounded: no wave can draw more
@@ -855,7 +899,21 @@ __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_t
             const unsigned long long dt = __builtin_readcyclecounter() - t0;
             F.tile_cost[tile] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
         }
+#ifdef MRT_LOOP_COUNTS
+        t_tiles += __builtin_readcyclecounter() - t0;
+#endif
     }
+#ifdef MRT_LOOP_COUNTS
+    if (lane == 0) {       // sites 18, 19: clocks until the scene copy is done | in tiles; the wave's whole life | 1
+        const unsigned long long t_exit = __builtin_readcyclecounter();
+        atomicAdd(&F.counters[kProfBase + 2 * 18], t_ready - t_enter);
+        atomicAdd(&F.counters[kProfBase + 2 * 18 + 1], t_tiles);
+        atomicAdd(&F.counters[kProfBase + 2 * 19], t_exit - t_enter);
+        atomicAdd(&F.counters[kProfBase + 2 * 19 + 1], 1ull);
+        atomicMax(&F.counters[kProfBase + 2 * 14], t_exit - t_enter);      // site 14: longest wave life | latest first-tile start
+        atomicMax(&F.counters[kProfBase + 2 * 14 + 1], t_ready - t_enter);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

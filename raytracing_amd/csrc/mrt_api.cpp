@@ -447,9 +447,9 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
             const uint32_t id = B.idx[k];
             const HostTri& t = B.tris[id];
             const f3 e1 = t.p1 - t.p0, e2 = t.p2 - t.p0;      // raytracer.cpp:289-290
-            triA[k] = make_float4(t.p0.x, t.p0.y, t.p0.z, e1.x);
-            triB[k] = make_float4(e1.y, e1.z, e2.x, e2.y);
-            triC[k] = make_float2(e2.z, bits2f(id));
+            triA[k] = make_float4(e1.x, e1.y, e1.z, e2.x);
+            triB[k] = make_float4(e2.y, e2.z, t.p0.x, t.p0.y);
+            triC[k] = make_float2(t.p0.z, bits2f(id));
         }
         for (size_t id = b; id < e; ++id) {
             const HostTri& t = B.tris[id];

@@ -15,7 +15,9 @@ SITES = {0: "nearest: inner-node step", 1: "nearest: leaf triangle", 2: "nearest
          12: "nearest: tri past back-face", 13: "nearest: tri exact tail",
          3: "shadow: work item", 4: "shadow: inner node", 5: "shadow: leaf triangle",
          6: "shared tri past back-face", 7: "shared tri exact tail",
-         8: "packet: work item", 9: "packet: inner visit", 10: "packet: leaf triangle", 11: "shader round"}
+         8: "packet: work item", 9: "packet: inner visit", 10: "packet: leaf triangle", 11: "shader round",
+         15: "shadow: inner node exact fallback", 14: "longest wave life | latest scene-copy end", 18: "sum: scene copy clocks | clocks in tiles", 19: "sum: wave life clocks | waves",
+         16: "clocks/16 in nearest-hit traversal", 17: "clocks/16 in direct light + shadow"}
 
 
 def main():
@@ -39,7 +41,7 @@ def main():
         rt.render_device(cam, fb.data_ptr(), args.w, mode=mode, stream=stream.cuda_stream)
         torch.cuda.synchronize()
         c = rt.ray_counts()
-        out = np.zeros(32, np.uint64)
+        out = np.zeros(40, np.uint64)
         L.mrt_debug_loop_counts(rt.h, out.ctypes.data_as(C.c_void_p))
         print("%s: %s" % (name, c))
         for s in sorted(SITES):
