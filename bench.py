@@ -3,16 +3,19 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-A step is ONE frame of the headline workload: the reference's default scene (maze, 2,120
+With one GPU a step is ONE frame of the headline workload: the reference's default scene (maze, 2,120
 triangles, one light) at 1920x1080 with the recursive reflection/refraction shader, default
 camera.  Scene, BVH and textures are resident in HBM before the timed region; the frame is
-written to a device-resident framebuffer.  With N > 1 the scene is replicated and every rank
-renders one such frame per step (N frames per step); finished frames are sent to rank 0 with
-grouped RCCL send/recv, overlapped with the next step's rendering ("scaling": "weak": per-GPU
-work is fixed).  A 1.5 ms frame is not cut into N pieces: single tiles of it take 0.1-0.9 ms, so
-a finer split is bound by tile latency, not throughput.  The configuration that IS split across
-GPUs, the 8K / 16 spp frame, is measured at every N as c4_8k_16spp (one frame per step,
-interleaved tile rows per rank, shares gathered on rank 0: strong scaling).
+written to a device-resident framebuffer.
+
+With N > 1 GPUs a step is ONE 7680x4320 frame at 16 samples per pixel (4x4 grid, packet path) of the
+same scene, split across the ranks: the scene is replicated, the frame's 8-row tile rows are dealt
+round-robin to the ranks, every rank but 0 renders its share packed and sends it with one RCCL
+send, rank 0 renders in place, receives and scatters ("scaling": "strong": total work is fixed).
+That configuration is measured at N = 1 too (c4_8k_16spp), so its scaling can be read off the N = 1
+line's c4_8k_16spp.value.  A 0.9 ms 1080p frame is not cut into N pieces -- single tiles of it take up
+to 0.6 ms, so a finer split is bound by tile latency; N whole frames per step, one per rank, are
+reported as c2_frames_per_rank at N > 1.
 
 Rank 0 prints one JSON line.  Besides the contract's keys it carries
   roofline      -- the dominant kernel against the fp32 VALU roofline (this path is neither
@@ -22,16 +25,16 @@ Rank 0 prints one JSON line.  Besides the contract's keys it carries
                    timed on this machine's host cores on the same workload (N = 1 only);
   packet_path   -- the reference's live Render path (64-ray packets + shadow rays) at 1080p,
                    GPU and CPU, which is the path the >= 50x target is stated on;
-  c4_8k_16spp   -- 7680x4320 with a 4x4 sample grid (packet path), the multi-GPU configuration:
-                   ONE frame per step split over the ranks, measured at every N so its strong
-                   scaling can be read from the same files;
+  c4_8k_16spp   -- the multi-GPU configuration (the headline itself at N > 1);
   c1_512_packet -- the reference's own 512x512 configuration, GPU and CPU;
   walking_camera -- the headline workload with a moving camera (the persistent kernel orders its tiles by the
                     previous frame's costs; a camera at rest is the best case of that);
   c3_1m_tris_4k -- synthetic 1,000,000-triangle soup at 3840x2160, packet path (scene in global
                    memory, divergent traversal);
-  c5_raster_1m_4k -- the rasterizer path on the same soup (rank 0 only; host framebuffer copy
-                   included because that path has no device-resident entry point).
+  c5_raster_1m_4k -- the rasterizer path on the same soup, device-resident frame.
+Every one of them carries a `roofline` object.  The reference algorithm's test counts of the configurations the
+CPU oracle cannot render inside a benchmark run (8K / 16 spp, 1 M triangles) are read from
+tests/golden/full_size.json, which tests/golden/make_full_size_goldens.py made with the oracle.
 """
 import argparse
 import json
@@ -214,14 +217,39 @@ def cpu_model():
     return "unknown"
 
 
-def oracle_work_and_baseline(scene, W, H, mode, cam, threads, budget_s):
+def host_cpus():
+    """What the host offers and what this job may use: the reference's pool is defined for at most 16 workers
+    (raytracer.cpp:449), which is also one GPU's share of a box's CPUs here."""
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = os.cpu_count() or 1
+    return {"cpu_model": cpu_model(), "cpus_visible": os.cpu_count() or 1, "cpus_allowed": allowed}
+
+
+def flops_of(c):
+    """Algorithmic flops of a frame from the reference algorithm's own test counts."""
+    return (FLOPS_SLAB * (c["packet_box"] + c["scalar_box"]) + FLOPS_TRI * (c["packet_tri"] + c["scalar_tri"])
+            + FLOPS_FIXED_PRIMARY * c["primary_rays"] + FLOPS_FIXED_SECONDARY * (c["shadow_rays"] + c["secondary_rays"]))
+
+
+def valu_roofline(flops, kernel_ms, kernel, **extra):
+    ach = flops / (kernel_ms * 1e-3) / 1e12
+    r = {"bound": "valu", "achieved": round(ach, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / VALU_PEAK_TFLOPS, 4),
+         "unfused_issue_peak": VALU_UNFUSED_TOPS, "frac_of_unfused_issue_rate": round(ach / VALU_UNFUSED_TOPS, 4),
+         "kernel": kernel, "kernel_ms": round(kernel_ms, 5), "algorithmic_flops_per_launch": int(flops)}
+    r.update(extra)
+    return r
+
+
+def oracle_work_and_baseline(scene, W, H, mode, cam, threads, budget_s, pinned=True):
     """Runs the CPU oracle on the same frame: work counters (reference algorithm) and a timed baseline."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     o = oracle_lib.Oracle()
     o.add_scene(scene)
     o.build_bvh()
-    o.set_threads(threads)
+    distinct = o.set_threads(threads, pinned=pinned)
     c = o.render(cam, W, H, mode=mode, want_ids=False, want_counters=True)["counters"]
     rays = c["primary_rays"] + c["shadow_rays"] + c["secondary_rays"]
     o.render(cam, W, H, mode=mode, want_ids=False)               # warm-up frame
@@ -231,9 +259,7 @@ def oracle_work_and_baseline(scene, W, H, mode, cam, threads, budget_s):
         r = o.render(cam, W, H, mode=mode, want_ids=False)
         best = min(best, time.perf_counter() - t0)
         frames += 1
-    flops = (FLOPS_SLAB * (c["packet_box"] + c["scalar_box"]) + FLOPS_TRI * (c["packet_tri"] + c["scalar_tri"])
-             + FLOPS_FIXED_PRIMARY * c["primary_rays"] + FLOPS_FIXED_SECONDARY * (c["shadow_rays"] + c["secondary_rays"]))
-    return {"counters": c, "rays": rays, "flops": flops, "best_s": best, "frames": frames, "fb": r["fb"]}
+    return {"counters": c, "rays": rays, "flops": flops_of(c), "best_s": best, "frames": frames, "fb": r["fb"], "distinct_cores": distinct}
 
 
 def main():
@@ -242,7 +268,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-extra", action="store_true", help="skip the packet-path and 8K sub-benchmarks")
+    ap.add_argument("--no-extra", action="store_true", help="skip the sub-benchmarks beside the headline")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -272,62 +298,85 @@ def main():
     scene = scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "maze.mrts"))
     cam = np.eye(4, dtype=np.float32).reshape(16)            # the reference's default camera
     W, H = 1920, 1080
+    with open(os.path.join(ROOT, "tests", "golden", "full_size.json")) as f:
+        golden = json.load(f)
+    metric = "Mrays/sec (primary+secondary) and ms/frame at 1080p/8K, 1/2/4/8 MI355X"
+    c4_workload = ("default maze scene (2120 triangles, 1 light), ONE 7680x4320 frame per step at 16 samples per pixel (4x4 grid: 30720x17280 "
+                   "traced), packet path + shadow rays, default camera; scene replicated, 8-row tile rows dealt round-robin to the ranks, "
+                   "shares gathered on rank 0 (RCCL send/recv)")
 
-    head = Workload("c2", scene, W, H, MODE_RECURSIVE, 1, cam, rank, world, torch, dist, split="frames")
-    res = head.run(args.steps, args.warmup)
-    out = {
-        "metric": "Mrays/sec (primary+secondary) and ms/frame at 1080p/8K, 1/2/4/8 MI355X",
-        "value": round(res["mrays_per_s"], 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(res["ms_per_step"], 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "default maze scene (2120 triangles, 1 light), 1920x1080, recursive reflection/refraction shader, "
-                               "default camera; one frame per GPU per step, scene replicated, frames gathered to rank 0 (RCCL send/recv)",
-                   "frames_per_step": world, "rays_per_frame": res["rays_per_step"] // world, "rays_per_step": res["rays_per_step"],
-                   "primary": res["primary"], "shadow": res["shadow"], "secondary": res["secondary"], "resolution": [W, H]},
-    }
+    def c4_roofline(r4):
+        g4 = golden["c4_maze_8k_16spp_packet"]["counters"]
+        assert g4["primary_rays"] + g4["shadow_rays"] == r4["rays_per_step"], "device ray counters disagree with the reference algorithm (8K / 16 spp)"
+        # the slowest rank's kernel renders 1/N of the frame's work
+        return valu_roofline(flops_of(g4) / world, r4["kernel_ms"], "render_tiles_global<packet>",
+                             counts="tests/golden/full_size.json (oracle, offline)", share_of_frame=1.0 / world)
 
-    if rehearsal and world > 1:
-        head._finish_pending()
-        torch.cuda.synchronize()
-        if rank == 0:
-            solo = torch.zeros((H, W), dtype=torch.int32, device="cuda")
-            head.rt.render_device(cam, solo.data_ptr(), W, mode=MODE_RECURSIVE, stream=torch.cuda.current_stream().cuda_stream)
-            torch.cuda.synchronize()
-            ok = all(bool(torch.equal(head.frames[r], solo)) for r in range(world))
-            print("rehearsal: %d gathered 1080p frames %s" % (world, "identical to a local render" if ok else "DIFFER"), file=sys.stderr)
-            assert ok
-    ora = None
-    if rank == 0:
-        threads = min(16, os.cpu_count() or 1)
+    out, threads = {}, min(16, host_cpus()["cpus_allowed"])
+    if world == 1:
+        head = Workload("c2", scene, W, H, MODE_RECURSIVE, 1, cam, rank, world, torch, dist, split="frames")
+        res = head.run(args.steps, args.warmup)
+        out = {
+            "metric": metric,
+            "value": round(res["mrays_per_s"], 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(res["ms_per_step"], 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "default maze scene (2120 triangles, 1 light), 1920x1080, recursive reflection/refraction shader, "
+                                   "default camera; one frame per step, device-resident framebuffer",
+                       "rays_per_frame": res["rays_per_step"], "rays_per_step": res["rays_per_step"],
+                       "primary": res["primary"], "shadow": res["shadow"], "secondary": res["secondary"], "resolution": [W, H],
+                       "multi_gpu": "with N > 1 the step is the 8K / 16 spp frame split across the ranks (c4_8k_16spp here is its N = 1 point)"},
+        }
+        g2 = golden["c2_maze_1080p_recursive"]
+        assert g2["counters"]["primary_rays"] + g2["counters"]["shadow_rays"] + g2["counters"]["secondary_rays"] == res["rays_per_step"], \
+            "device ray counters disagree with the reference algorithm"
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-                traffic = json.load(f).get("render_tiles_recursive_1080p_bytes_per_launch")
+                tj = json.load(f)
+            traffic, traffic_src = tj.get("render_tiles_recursive_1080p_bytes_per_launch"), \
+                "profiles/hbm_traffic.json: FETCH_SIZE + WRITE_SIZE of a rocprofv3 --pmc pass (profile %s), not measured during this run" % tj.get("profile")
         except (OSError, ValueError):
-            traffic = None
-        if not args.no_cpu and world == 1:
+            traffic, traffic_src = None, None
+        out["roofline"] = valu_roofline(flops_of(g2["counters"]), res["kernel_ms"], "render_tiles_resident<recursive>", traffic=traffic, traffic_source=traffic_src,
+                                        hbm={"algorithmic_bytes_per_launch": 4 * W * H, "achieved_GBps": round(4 * W * H / (res["kernel_ms"] * 1e-3) / 1e9, 2), "peak_GBps": 8000})
+        got = head.frame()
+        out["parity"] = {"frame_hash_equals_oracle": _fbsum(got) == g2["fbsum"]}
+        assert out["parity"]["frame_hash_equals_oracle"], "the headline frame differs from the oracle's"
+        if not args.no_cpu:
             ora = oracle_work_and_baseline(scene, W, H, MODE_RECURSIVE, cam, threads, args.cpu_seconds)
-            assert ora["rays"] == res["rays_per_step"], "device ray counters disagree with the reference algorithm"
-            out["cpu_baseline"] = {"value": round(ora["rays"] / ora["best_s"] / 1e6, 3), "unit": "Mrays/s", "cores": threads,
-                                   "kind": "port", "sample": "%d full 1920x1080 frames of the same workload, best frame "
-                                   "(tile pool of %d threads, -O2 -ffp-contract=off)" % (ora["frames"], threads),
-                                   "ms_per_frame": round(ora["best_s"] * 1e3, 2), "cpu_model": cpu_model()}
-            a8 = head.frame().view(np.uint8).reshape(-1, 4).astype(np.int16)
+            assert ora["rays"] == res["rays_per_step"] and ora["counters"] == g2["counters"]
+            out["cpu_baseline"] = dict({"value": round(ora["rays"] / ora["best_s"] / 1e6, 3), "unit": "Mrays/s", "cores": threads,
+                                        "kind": "port", "sample": "%d full 1920x1080 frames of the same workload, best frame (tile pool of %d worker threads "
+                                        "pinned to %d distinct physical cores, -O2 -ffp-contract=off)" % (ora["frames"], threads, ora["distinct_cores"]),
+                                        "ms_per_frame": round(ora["best_s"] * 1e3, 2), "distinct_physical_cores": ora["distinct_cores"],
+                                        "all_cores_note": "16 workers is the most the reference's pool is defined for (raytracer.cpp:449) and the CPU share of "
+                                                          "one GPU on this host, so the all-cores figure is this one"}, **host_cpus())
+            a8 = got.view(np.uint8).reshape(-1, 4).astype(np.int16)
             b8 = ora["fb"].view(np.uint8).reshape(-1, 4).astype(np.int16)
-            out["parity"] = {"pixels_beyond_1_255": float((np.abs(a8 - b8).max(axis=1) > 1).mean()),
-                             "pixels_different": int((a8 != b8).any(axis=1).sum())}
-            flops = ora["flops"]
-        else:
-            flops = None
-        if flops is not None and res["kernel_ms"] > 0:
-            ach = flops / (res["kernel_ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "valu", "achieved": round(ach, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / VALU_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "unfused_issue_peak": VALU_UNFUSED_TOPS, "frac_of_unfused_issue_rate": round(ach / VALU_UNFUSED_TOPS, 4),
-                               "kernel": "render_tiles<recursive>", "kernel_ms": round(res["kernel_ms"], 5),
-                               "algorithmic_flops_per_launch": int(flops),
-                               "hbm": {"algorithmic_bytes_per_launch": 4 * W * H, "achieved_GBps": round(4 * W * H / (res["kernel_ms"] * 1e-3) / 1e9, 2), "peak_GBps": 8000}}
+            out["parity"].update({"pixels_beyond_1_255": float((np.abs(a8 - b8).max(axis=1) > 1).mean()), "pixels_different": int((a8 != b8).any(axis=1).sum())})
+    else:
+        head = Workload("c4", scene, 7680, 4320, MODE_PACKET, 4, cam, rank, world, torch, dist, split="rows")
+        res = head.run(args.steps, args.warmup)
+        if rank == 0:
+            out = {
+                "metric": metric,
+                "value": round(res["mrays_per_s"], 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(res["ms_per_step"], 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": c4_workload, "rays_per_frame": res["rays_per_step"], "rays_per_step": res["rays_per_step"],
+                           "primary": res["primary"], "shadow": res["shadow"], "secondary": res["secondary"], "resolution": [7680, 4320], "spp": 16,
+                           "single_gpu_point": "c4_8k_16spp.value of the N = 1 line (whose headline is the 1080p recursive frame)"},
+                "roofline": c4_roofline(res),
+            }
+        if rehearsal:
+            got = head.frame() if rank == 0 else None
+            if rank == 0:
+                ok = _fbsum(got) == golden["c4_maze_8k_16spp_packet"]["fbsum"]
+                print("rehearsal: 8K frame assembled from %d interleaved shares %s" % (world, "equals the oracle's frame" if ok else "DIFFERS"), file=sys.stderr)
+                assert ok
+        del head
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_extra:
         fbh = np.zeros((H, W), np.uint32)
         head.rt.render(cam, mode=MODE_RECURSIVE, want_ids=False, fb=fbh)
         t0 = time.perf_counter()
@@ -384,41 +433,47 @@ def main():
         out["walking_camera"] = {"ms_per_frame": round(walk_s / 100 * 1e3, 4), "value": round(walk_rays / walk_s / 1e6, 3), "unit": "Mrays/s",
                                  "what": "the headline workload with the camera moving 0.16 units per frame (never `value`): the tile "
                                          "order of each frame comes from the costs measured in the previous, different frame"}
-    if not args.no_extra:
+    if world == 1:
+        del head
+    if not args.no_extra and world == 1:
         c4 = Workload("c4", scene, 7680, 4320, MODE_PACKET, 4, cam, rank, world, torch, dist, split="rows")
         r4 = c4.run(max(2, min(args.steps, 5)), 1)
-        if rehearsal and world > 1:
-            got = c4.frame() if rank == 0 else None
-            if rank == 0:
-                solo = torch.zeros((4320, 7680), dtype=torch.int32, device="cuda")
-                c4.rt.render_device(cam, solo.data_ptr(), 7680, mode=MODE_PACKET, spp_grid=4, stream=torch.cuda.current_stream().cuda_stream)
-                torch.cuda.synchronize()
-                ok = np.array_equal(got, solo.cpu().numpy().view(np.uint32))
-                print("rehearsal: 8K frame assembled from %d interleaved shares %s" % (world, "identical to a local render" if ok else "DIFFERS"),
-                      file=sys.stderr)
-                assert ok
-        if rank == 0:
-            out["c4_8k_16spp"] = {"workload": "same scene, ONE 7680x4320 frame per step, 4x4 sample grid (30720x17280 traced), packet path; "
-                                              "tile rows dealt round-robin to the ranks, shares gathered on rank 0",
-                                  "scaling": "strong", "value": round(r4["mrays_per_s"], 3), "unit": "Mrays/s",
-                                  "ms_per_frame": round(r4["ms_per_step"], 4), "kernel_ms": round(r4["kernel_ms"], 4),
-                                  "rays_per_frame": r4["rays_per_step"]}
+        out["c4_8k_16spp"] = {"workload": c4_workload, "scaling": "strong", "value": round(r4["mrays_per_s"], 3), "unit": "Mrays/s",
+                              "ms_per_frame": round(r4["ms_per_step"], 4), "kernel_ms": round(r4["kernel_ms"], 4),
+                              "rays_per_frame": r4["rays_per_step"], "roofline": c4_roofline(r4),
+                              "frame_hash_equals_oracle": _fbsum(c4.frame()) == golden["c4_maze_8k_16spp_packet"]["fbsum"]}
+        assert out["c4_8k_16spp"]["frame_hash_equals_oracle"]
         del c4
+    if not args.no_extra and world > 1:
+        # N whole 1080p recursive frames per step, one per rank, gathered on rank 0 (what a frame loop does with frames too small to cut)
+        fr = Workload("c2", scene, W, H, MODE_RECURSIVE, 1, cam, rank, world, torch, dist, split="frames")
+        rf = fr.run(args.steps, args.warmup)
+        if rank == 0:
+            out["c2_frames_per_rank"] = {"workload": "the N = 1 headline workload, one whole 1920x1080 recursive frame per rank and step, frames gathered on rank 0",
+                                         "scaling": "weak", "value": round(rf["mrays_per_s"], 3), "unit": "Mrays/s", "ms_per_step": round(rf["ms_per_step"], 5),
+                                         "kernel_ms": round(rf["kernel_ms"], 5), "frames_per_step": world}
+        if rehearsal and rank == 0:
+            fr._finish_pending()
+            torch.cuda.synchronize()
+            ok = all(_fbsum(fr.frames[r].cpu().numpy().view(np.uint32)) == golden["c2_maze_1080p_recursive"]["fbsum"] for r in range(world))
+            print("rehearsal: %d gathered 1080p frames %s" % (world, "equal the oracle's frame" if ok else "DIFFER"), file=sys.stderr)
+            assert ok
+        del fr
     if not args.no_extra and world == 1:
         pk = Workload("packet1080p", scene, W, H, MODE_PACKET, 1, cam, rank, world, torch, dist)
         rp = pk.run(args.steps, args.warmup)
+        gp = golden["c2_maze_1080p_packet"]
+        assert _fbsum(pk.frame()) == gp["fbsum"] and gp["counters"]["primary_rays"] + gp["counters"]["shadow_rays"] == rp["rays_per_step"]
         out["packet_path"] = {"workload": "same scene, 1920x1080, 64-ray packets + shadow rays (Raytracer::Render)",
                               "value": round(rp["mrays_per_s"], 3), "unit": "Mrays/s", "ms_per_step": round(rp["ms_per_step"], 5),
-                              "kernel_ms": round(rp["kernel_ms"], 5), "rays_per_frame": rp["rays_per_step"]}
+                              "kernel_ms": round(rp["kernel_ms"], 5), "rays_per_frame": rp["rays_per_step"],
+                              "roofline": valu_roofline(flops_of(gp["counters"]), rp["kernel_ms"], "render_tiles_global<packet>")}
         if not args.no_cpu:
             op = oracle_work_and_baseline(scene, W, H, MODE_PACKET, cam, threads, max(3.0, args.cpu_seconds / 3))
             out["packet_path"]["cpu_value"] = round(op["rays"] / op["best_s"] / 1e6, 3)
             out["packet_path"]["cpu_ms_per_frame"] = round(op["best_s"] * 1e3, 2)
             out["packet_path"]["cpu_cores"] = threads
-            if rp["kernel_ms"] > 0:
-                ach = op["flops"] / (rp["kernel_ms"] * 1e-3) / 1e12
-                out["packet_path"]["roofline"] = {"bound": "valu", "achieved": round(ach, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                                  "frac": round(ach / VALU_PEAK_TFLOPS, 4), "frac_of_unfused_issue_rate": round(ach / VALU_UNFUSED_TOPS, 4)}
+            out["packet_path"]["speedup_over_cpu"] = round(rp["mrays_per_s"] / out["packet_path"]["cpu_value"], 1)
         del pk
         c1 = Workload("c1", scene, 512, 512, MODE_PACKET, 1, cam, rank, world, torch, dist)
         r1 = c1.run(args.steps, args.warmup)
@@ -430,31 +485,68 @@ def main():
             out["c1_512_packet"]["cpu_value"] = round(o1["rays"] / o1["best_s"] / 1e6, 3)
             out["c1_512_packet"]["cpu_ms_per_frame"] = round(o1["best_s"] * 1e3, 3)
             out["c1_512_packet"]["cpu_cores"] = threads
+            out["c1_512_packet"]["roofline"] = valu_roofline(o1["flops"], r1["kernel_ms"], "render_tiles_global<packet>")
             assert o1["rays"] == r1["rays_per_step"] and np.array_equal(c1.frame(), o1["fb"])
         del c1
-        soup = scene_io.soup_scene(1000000)
+        soup = scene_io.large_scene(scene)
         c3 = Workload("c3", soup, 3840, 2160, MODE_PACKET, 1, cam, rank, world, torch, dist)
         r3 = c3.run(max(2, min(args.steps, 10)), 2)
-        out["c3_1m_tris_4k"] = {"workload": "synthetic 1,000,000-triangle soup (LCG seed 12345), 3840x2160, packet path + shadow rays",
+        g3 = golden["c3_soup1m_4k_packet"]
+        k3 = g3["counters"]
+        assert _fbsum(c3.frame()) == g3["fbsum"] and k3["primary_rays"] + k3["shadow_rays"] == r3["rays_per_step"]
+        # bytes the reference algorithm fetches: a packet reads a node (32 B) or a leaf's triangles (36 B each) once for all
+        # its rays, a single ray (shadow rays) once per ray; plus the pixels
+        n_packets = (3840 // 8) * (2160 // 8)
+        node_fetch = 2 * (k3["packet_nodes"] - k3["packet_leaves"]) + n_packets
+        bytes3 = 32 * (node_fetch + k3["scalar_box"]) + 36 * (k3["packet_trifetch"] + k3["scalar_tri"]) + 4 * 3840 * 2160
+        gbps3 = bytes3 / (r3["kernel_ms"] * 1e-3) / 1e9
+        out["c3_1m_tris_4k"] = {"workload": "synthetic 1,000,000-triangle soup (LCG seed 12345, grass texture), 3840x2160, packet path + shadow rays",
                                 "value": round(r3["mrays_per_s"], 3), "unit": "Mrays/s", "ms_per_step": round(r3["ms_per_step"], 4),
-                                "kernel_ms": round(r3["kernel_ms"], 4), "rays_per_frame": r3["rays_per_step"]}
-        from raytracing_amd.binding import HostFrame
-        hf = HostFrame(2160, 3840)
-        hf.array[:] = 0
-        c3.rt.raster(cam, fb=hf.array, want_z=False, want_ids=False)
+                                "kernel_ms": round(r3["kernel_ms"], 4), "rays_per_frame": r3["rays_per_step"], "frame_hash_equals_oracle": True,
+                                "roofline": {"bound": "hbm", "achieved": round(gbps3, 2), "peak": 8000, "unit": "GB/s", "frac": round(gbps3 / 8000, 4),
+                                             "traffic": None, "kernel": "render_tiles_global<packet>", "kernel_ms": round(r3["kernel_ms"], 4),
+                                             "algorithmic_bytes_per_launch": int(bytes3),
+                                             "bytes_model": "32 B x (packet node fetches + single-ray box tests) + 36 B x (packet leaf triangles + single-ray triangle tests) + 4 B per pixel",
+                                             "valu": valu_roofline(flops_of(k3), r3["kernel_ms"], "render_tiles_global<packet>"),
+                                             "counts": "tests/golden/full_size.json (oracle, offline)"}}
+        # the rasterizer on the same scene, frame resident in device memory: kernels only
+        fbr = torch.zeros((2160, 3840), dtype=torch.int32, device="cuda")
+        st = torch.cuda.current_stream()
+        for _ in range(3):
+            c3.rt.raster_device(cam, fbr.data_ptr(), 3840, stream=st.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        e0.record(st)
         for _ in range(10):
-            c3.rt.raster(cam, fb=hf.array, want_z=False, want_ids=False)
-        out["c5_raster_1m_4k"] = {"workload": "rasterizer path, same soup, 3840x2160, frame written into page-locked host memory "
-                                              "(the rasterizer has no device-resident entry point)",
-                                  "ms_per_frame": round((time.perf_counter() - t0) / 10 * 1e3, 3),
-                                  "covered_fraction": round(float((hf.array != 0).mean()), 4)}
-        hf.close()
+            c3.rt.raster_device(cam, fbr.data_ptr(), 3840, stream=st.cuda_stream)
+        e1.record(st)
+        torch.cuda.synchronize()
+        wall5 = (time.perf_counter() - t0) / 10 * 1e3
+        kern5 = e0.elapsed_time(e1) / 10
+        g5 = golden["c5_soup1m_4k_raster"]
+        covered = int((fbr != 0).sum())
+        bytes5 = 8 * g5["fragments"] + 36 * g5["triangles_drawn"]
+        gbps5 = bytes5 / (kern5 * 1e-3) / 1e9
+        out["c5_raster_1m_4k"] = {"workload": "rasterizer path, same soup, 3840x2160, frame resident in device memory (mrt_raster_render_device)",
+                                  "ms_per_frame": round(wall5, 4), "kernel_ms": round(kern5, 4), "covered_fraction": round(covered / (3840 * 2160), 4),
+                                  "covered_pixels_vs_reference_rasterizer": [covered, g5["covered_pixels"]],
+                                  "roofline": {"bound": "hbm", "achieved": round(gbps5, 2), "peak": 8000, "unit": "GB/s", "frac": round(gbps5 / 8000, 4),
+                                               "traffic": None, "kernel": "raster_setup + bin + raster_tile (whole frame)", "kernel_ms": round(kern5, 4),
+                                               "algorithmic_bytes_per_launch": int(bytes5),
+                                               "bytes_model": "8 B x fragments the reference's span fill visits (%d) + 36 B x triangles it draws (%d)" % (g5["fragments"], g5["triangles_drawn"]),
+                                               "counts": "tests/golden/full_size.json (oracle, offline)"}}
+        del c3
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _fbsum(fb):
+    """Frame checksum of tests/golden/full_size.json: sum of pixel[i] * (i + 1) mod 2^64 (row-major)."""
+    px = np.ascontiguousarray(fb, np.uint32).reshape(-1).astype(np.uint64)
+    return "%016x" % int((px * np.arange(1, px.size + 1, dtype=np.uint64)).sum(dtype=np.uint64))
 
 
 if __name__ == "__main__":

@@ -191,6 +191,13 @@ int mrt_part_rows(int height, int part, int n_parts, int block_tile_rows);
 int mrt_raster_render(mrt_ctx* ctx, const float cam_to_world[16],
                       uint32_t* fb, int pitch_px, float* zbuf, int32_t* tri_ids);
 
+/* The same frame into DEVICE memory, on `stream`: fb_dev (rows of pitch_px pixels, covered pixels only are
+ * written), zbuf_dev and tri_ids_dev (optional, width*height each; every pixel written).  Returns when the
+ * frame is complete: the call reads back the length of the frame's triangle lists to make sure its buffer was
+ * large enough (and renders once more if a frame needs a longer list than any before it). */
+int mrt_raster_render_device(mrt_ctx* ctx, const float cam_to_world[16],
+                             void* fb_dev, int pitch_px, void* zbuf_dev, void* tri_ids_dev, void* stream);
+
 /* ---- operator-level seam ------------------------------------------------------------ */
 
 /* BVH::TraverseRayPacket (raytracer.h:352; raytracer.cpp:1349-1464) on caller-made packets.

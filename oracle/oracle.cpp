@@ -21,6 +21,8 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <pthread.h>
+#include <sched.h>
 #include <vector>
 
 namespace ora {
@@ -56,11 +58,12 @@ struct Counters {
     uint64_t packet_box = 0, packet_tri = 0, packet_nodes = 0, packet_leaves = 0;
     uint64_t scalar_box = 0, scalar_tri = 0, scalar_nodes = 0, scalar_rays = 0;
     uint64_t primary_rays = 0, shadow_rays = 0, secondary_rays = 0;
+    uint64_t packet_trifetch = 0;      // triangles of the leaves a packet visits, counted once per visit (not per ray)
     void add(const Counters& o) {
         packet_box += o.packet_box; packet_tri += o.packet_tri; packet_nodes += o.packet_nodes;
         packet_leaves += o.packet_leaves; scalar_box += o.scalar_box; scalar_tri += o.scalar_tri;
         scalar_nodes += o.scalar_nodes; scalar_rays += o.scalar_rays; primary_rays += o.primary_rays;
-        shadow_rays += o.shadow_rays; secondary_rays += o.secondary_rays;
+        shadow_rays += o.shadow_rays; secondary_rays += o.secondary_rays; packet_trifetch += o.packet_trifetch;
     }
 };
 static thread_local Counters* g_ctr = nullptr;
@@ -360,7 +363,7 @@ struct HitPacket { int tri[PACKETSIZE]; float u[PACKETSIZE], v[PACKETSIZE]; };
 
 // raytracer.cpp:1445-1464
 static void leaf_packet(const BVH& b, const Node& n, RayPacket& p, HitPacket& res, int firstActive) {
-    if (g_ctr) g_ctr->packet_leaves++;
+    if (g_ctr) { g_ctr->packet_leaves++; g_ctr->packet_trifetch += n.count; }
     for (int iRay = firstActive; iRay < PACKETSIZE; ++iRay) {
         float u, v;
         for (uint32_t i = n.firstLeft; i < n.firstLeft + n.count; ++i) {
@@ -621,11 +624,59 @@ static void render_tile(const Tracer& T, const Frame& f, int startx, int starty)
 
 // threads.cpp:101-169 -- a pool of parked workers; each Render wakes them all and every worker
 // pulls tile numbers by decrementing one shared counter until it drops below 1.
+// CPUs this process may run on, one per physical core first (the lowest-numbered hardware thread of each core),
+// then the remaining hardware threads: pinning worker i to entry i keeps the first workers on distinct cores.
+static std::vector<int> cpus_one_per_core_first() {
+    std::vector<int> firsts, others;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) != 0) return firsts;
+    for (int c = 0; c < CPU_SETSIZE; ++c) {
+        if (!CPU_ISSET(c, &set)) continue;
+        char path[128];
+        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+        int lowest = c;
+        if (FILE* f = fopen(path, "r")) {
+            if (fscanf(f, "%d", &lowest) != 1) lowest = c;
+            fclose(f);
+        }
+        (lowest == c ? firsts : others).push_back(c);
+    }
+    firsts.insert(firsts.end(), others.begin(), others.end());
+    return firsts;
+}
+
 class TilePool {
 public:
-    explicit TilePool(int n) : nthreads_(n) {
-        for (int i = 0; i < n; ++i) workers_.emplace_back([this, i] { loop(i); });
+    // pin: worker i stays on the i-th CPU of cpus_one_per_core_first() (a timing aid; results do not depend on it)
+    explicit TilePool(int n, bool pin = false) : nthreads_(n) {
+        const std::vector<int> cpus = pin ? cpus_one_per_core_first() : std::vector<int>();
+        for (int i = 0; i < n; ++i) {
+            workers_.emplace_back([this, i] { loop(i); });
+            if (!cpus.empty()) {
+                cpu_set_t one;
+                CPU_ZERO(&one);
+                CPU_SET(cpus[i % cpus.size()], &one);
+                if (pthread_setaffinity_np(workers_.back().native_handle(), sizeof one, &one) == 0) ++pinned_;
+            }
+        }
+        distinct_cores_ = 0;
+        if (!cpus.empty()) {
+            // entries before the first repeated core are distinct cores
+            std::vector<int> firsts = cpus_one_per_core_first();
+            int n_first = 0;
+            for (int c : firsts) {
+                char path[128];
+                snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+                int lowest = c;
+                if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &lowest) != 1) lowest = c; fclose(f); }
+                if (lowest == c) ++n_first;
+            }
+            distinct_cores_ = n < n_first ? n : n_first;
+        }
     }
+    int pinned() const { return pinned_; }
+    int distinct_cores() const { return distinct_cores_; }
     ~TilePool() {
         { std::lock_guard<std::mutex> l(m_); quit_ = true; gen_++; }
         cv_.notify_all();
@@ -667,7 +718,7 @@ private:
         }
     }
     struct XY { int x, y; };
-    int nthreads_;
+    int nthreads_, pinned_ = 0, distinct_cores_ = 0;
     std::vector<std::thread> workers_;
     std::vector<XY> tiles_;
     std::atomic<long> waiting_{0};
@@ -685,6 +736,9 @@ private:
 // ------------------------------------------------------------------------------------------
 struct Raster {
     int W, H;
+    // work of the last frame as the reference algorithm does it: span pixels visited (the depth test of
+    // rasterizer.cpp:177 runs once per such fragment) and triangles that reached the span fill
+    uint64_t fragments = 0, fragments_drawn = 0, triangles_drawn = 0;
     vec4 frustum[5];
     std::vector<float> zbuffer;
     std::vector<float> xleft, xright, uleft, uright, vleft, vright, zleft, zright;
@@ -786,6 +840,7 @@ static void raster_mesh(Raster& R, const Scene& S, const mat4& transform, const 
             }
             miny = gmin(miny, iy0); maxy = gmax(maxy, iy1);
         }
+        R.triangles_drawn++;
         for (int y = miny; y <= maxy; R.xleft[y] = (float)(W - 1), R.xright[y++] = 0) {
             float x0 = R.xleft[y], x1 = R.xright[y], rxdiff = 1.0f / (x1 - x0);
             float u0 = R.uleft[y], du = (R.uright[y] - u0) * rxdiff;
@@ -796,8 +851,10 @@ static void raster_mesh(Raster& R, const Scene& S, const mat4& transform, const 
             u0 += ff * du; v0 += ff * dv; z0 += ff * dz;
             uint32_t* dest = fb + (size_t)y * W;
             float* zbuf = zbuffer + (size_t)y * W;
+            if (ix1 >= ix0) R.fragments += (uint64_t)(ix1 - ix0 + 1);
             for (int x = ix0; x <= ix1; x++, u0 += du, v0 += dv, z0 += dz) {
                 if (z0 >= zbuf[x]) continue;
+                R.fragments_drawn++;
                 const float z = 1.0f / z0;
                 const int u = (int)(u0 * z * tw) & umask, v = (int)(v0 * z * th) & vmask;
                 dest[x] = pal[src[u + v * (umask + 1)]]; zbuf[x] = z0;
@@ -1140,6 +1197,12 @@ uint64_t ora_fbhash(const uint32_t* fb, int64_t n) {
     for (int64_t i = 0; i < n; ++i) h = fold(h, fb[i]);
     return h;
 }
+// the same fold continued from h0: the hash of a frame from its row bands, top to bottom
+uint64_t ora_fbhash_from(uint64_t h0, const uint32_t* fb, int64_t n) {
+    uint64_t h = h0;
+    for (int64_t i = 0; i < n; ++i) h = fold(h, fb[i]);
+    return h;
+}
 // sum over packets (tile order y-major, x-minor), k = ray index inside the 8x8 tile
 uint64_t ora_idsum(const int32_t* hit_ids, int W, int H) {
     uint64_t s = 0;
@@ -1165,15 +1228,23 @@ void ora_view_plane(const float* cam16, int W, int H, float* out11) {
 }
 
 void ora_set_threads(Context* c, int n) {
-    if (c->pool && c->pool->size() == n) return;
+    if (c->pool && c->pool->size() == n && c->pool->pinned() == 0) return;
     delete c->pool;
     c->pool = new TilePool(n);
+}
+// The same pool with every worker pinned to its own CPU, distinct physical cores first (sched affinity of the
+// worker threads only: the calling thread and the rest of the process keep theirs).  Returns the number of
+// distinct physical cores the workers sit on; 0 if pinning was not possible.
+int ora_set_threads_pinned(Context* c, int n) {
+    delete c->pool;
+    c->pool = new TilePool(n, true);
+    return c->pool->pinned() == n ? c->pool->distinct_cores() : 0;
 }
 // mode 0 = packet path (Raytracer::Render), 1 = recursive shader per pixel.  Rows [y_begin,y_end)
 // only (multiples of 8).  spp_grid g > 1: the frame is rendered by the reference algorithm at
 // (W*g) x (H*g) and each output pixel is the per-channel mean (rounded down) of its g x g block
 // of quantised pixels; hit_ids/tuv then describe the (W*g) x (H*g) image.
-// counters_out: 11 x uint64 or NULL.
+// counters_out: 12 x uint64 or NULL.
 int ora_render(Context* c, const float* cam16, int W, int H, int mode, int spp_grid, int y_begin, int y_end,
                uint32_t* fb, int pitch, int32_t* hit_ids, float* tuv, uint64_t* counters_out) {
     const int g = spp_grid < 1 ? 1 : spp_grid;
@@ -1254,6 +1325,7 @@ int ora_raster_render(Context* c, const float* cam16, int W, int H, uint32_t* fb
     if (!c->raster || c->raster->W != W || c->raster->H != H) { delete c->raster; c->raster = raster_init(W, H); }
     Raster& R = *c->raster;
     std::fill(R.zbuffer.begin(), R.zbuffer.end(), 0.0f);           // rasterizer.cpp:55
+    R.fragments = R.fragments_drawn = R.triangles_drawn = 0;
     mat4 cam; memcpy(&cam, cam16, 64);
     mat4 inv = inverse(cam);                                        // rasterizer.cpp:57
     // rasterizer.cpp:65-72: scene root -> OBJ root -> group -> mesh, all identity local transforms
@@ -1263,6 +1335,13 @@ int ora_raster_render(Context* c, const float* cam16, int W, int H, uint32_t* fb
     for (auto& m : c->scene.meshes) { raster_mesh(R, c->scene, M, m, base, fb, tri_ids); base += m.tris; }
     if (zbuf_out) memcpy(zbuf_out, R.zbuffer.data(), sizeof(float) * (size_t)W * H);
     return 0;
+}
+
+// out[0] span pixels visited, out[1] of them passing the depth test, out[2] triangles that reached the span fill -- last ora_raster_render
+void ora_raster_work(Context* c, uint64_t* out) {
+    out[0] = c->raster ? c->raster->fragments : 0;
+    out[1] = c->raster ? c->raster->fragments_drawn : 0;
+    out[2] = c->raster ? c->raster->triangles_drawn : 0;
 }
 
 }  // extern "C"

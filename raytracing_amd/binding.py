@@ -20,7 +20,7 @@ MODE_RECURSIVE = 1
 SYMBOLS = ("mrt_create", "mrt_destroy", "mrt_last_error", "mrt_version", "mrt_scene_upload", "mrt_scene_upload_lbvh",
            "mrt_set_lights",
            "mrt_bvh_build_host", "mrt_render", "mrt_host_alloc", "mrt_host_free", "mrt_render_submit", "mrt_render_wait", "mrt_render_device", "mrt_render_device_noalloc", "mrt_render_device_part", "mrt_part_rows",
-           "mrt_raster_render", "mrt_trace_packets",
+           "mrt_raster_render", "mrt_raster_render_device", "mrt_trace_packets",
            "mrt_trace_rays", "mrt_get_ray_counts", "mrt_camera_look_at")
 
 
@@ -87,6 +87,7 @@ def lib():
         L.mrt_render_device_part.argtypes = [vp, vp, C.c_uint32, i32, i32, i32, i32, vp, i32, vp, vp]
         L.mrt_part_rows.argtypes = [i32, i32, i32, i32]
         L.mrt_raster_render.argtypes = [vp, vp, vp, i32, vp, vp]
+        L.mrt_raster_render_device.argtypes = [vp, vp, vp, i32, vp, vp, vp]
         L.mrt_trace_packets.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
         L.mrt_trace_rays.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
         L.mrt_get_ray_counts.argtypes = [vp, vp]
@@ -283,6 +284,13 @@ class Raytracer:
         ids = np.full((self.height, self.width), -1, np.int32) if want_ids else None
         self._check(self.L.mrt_raster_render(self.h, _p(cam), _p(fb), fb.strides[0] // 4, _p(z), _p(ids)), "mrt_raster_render")
         return fb, z, ids
+
+    def raster_device(self, cam, fb_ptr, pitch, z_ptr=None, ids_ptr=None, stream=None):
+        """Rasterizer::Render(camera) into device memory (raw pointers)."""
+        cam = np.ascontiguousarray(getattr(cam, "transform", cam), np.float32).reshape(16)
+        self._check(self.L.mrt_raster_render_device(self.h, _p(cam), C.c_void_p(fb_ptr), pitch, C.c_void_p(z_ptr) if z_ptr else None,
+                                                    C.c_void_p(ids_ptr) if ids_ptr else None, C.c_void_p(stream) if stream else None),
+                    "mrt_raster_render_device")
 
     def trace_packets(self, O, D, rD, t):
         """BVH::TraverseRayPacket on (n_packets, 64, 3) ray arrays; returns (t, tri, u, v)."""

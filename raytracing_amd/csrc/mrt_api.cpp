@@ -759,7 +759,21 @@ int mrt_raster_render(mrt_ctx* c, const float cam[16], uint32_t* fb, int pitch_p
     MRT_HIP(c, hipSetDevice(c->device));
     std::string err;
     RasterTextures tx{c->d_tex.p, c->d_texels.p, c->d_pal.p};
-    if (int rc = raster_render(c->raster, tx, c->width, c->height, cam, fb, pitch_px, zbuf, tri_ids, c->stream, err))
+    if (int rc = raster_render(c->raster, tx, c->width, c->height, cam, fb, pitch_px, zbuf, tri_ids, false, c->stream, err))
+        return fail(c, rc, err);
+    return MRT_OK;
+}
+
+int mrt_raster_render_device(mrt_ctx* c, const float cam[16], void* fb_dev, int pitch_px, void* zbuf_dev, void* tri_ids_dev, void* stream) {
+    if (!c) return MRT_E_ARG;
+    if (!cam || !fb_dev) return fail(c, MRT_E_ARG, "null camera or framebuffer");
+    if (!c->has_scene) return fail(c, MRT_E_STATE, "mrt_scene_upload has not been called");
+    if (pitch_px < c->width) return fail(c, MRT_E_ARG, "pitch smaller than width");
+    MRT_HIP(c, hipSetDevice(c->device));
+    std::string err;
+    RasterTextures tx{c->d_tex.p, c->d_texels.p, c->d_pal.p};
+    if (int rc = raster_render(c->raster, tx, c->width, c->height, cam, (uint32_t*)fb_dev, pitch_px, (float*)zbuf_dev, (int32_t*)tri_ids_dev, true,
+                               (hipStream_t)stream, err))
         return fail(c, rc, err);
     return MRT_OK;
 }

@@ -87,6 +87,37 @@ __device__ __forceinline__ TileRange bin_range(uint2 b) {
     return TileRange{(int)(b.x & 0xfffu), (int)((b.x >> 12) & 0xfffu), (int)(b.y & 0xfffu), (int)((b.y >> 12) & 0xfffu)};
 }
 
+// A convex polygon in view space with its texture coordinates.  A triangle gains at most one corner per clip
+// plane and two planes are applied (the near plane and one side plane: rasterizer.cpp:119 stops at p < 2).
+struct ClipPoly {
+    static constexpr int kMax = 8;
+    f3 p[kMax];
+    f2 t[kMax];
+    int n;
+    __device__ __forceinline__ void add(f3 pos, f2 uv) { if (n < kMax) { p[n] = pos; t[n] = uv; ++n; } }
+};
+// The part of `in` on the inner side of the plane dot(normal, x) = offset (rasterizer.cpp:117-133).  The polygon is
+// walked edge by edge; an edge that crosses the plane contributes the crossing point A + s (B - A) with
+// s = da / (da - db), an edge that ends inside contributes its end corner -- in that order, which is the
+// reference's, so the corner order of the result (and with it the vertex triple the attribute planes are fitted
+// to further down) is the reference's too.  "Inside" is da >= 0 and "outside" da < 0 as two separate tests: a
+// NaN distance is neither, and such an edge contributes nothing.
+__device__ __forceinline__ ClipPoly clip_against(const ClipPoly& in, f3 normal, float offset) {
+    ClipPoly out;
+    out.n = 0;
+    for (int j = 0; j < in.n; ++j) {
+        const int k = j + 1 == in.n ? 0 : j + 1;
+        const float da = dot(normal, in.p[j]) - offset, db = dot(normal, in.p[k]) - offset;
+        const bool a_in = da >= 0, a_out = da < 0, b_in = db >= 0, b_out = db < 0;
+        if ((a_out && b_in) || (a_in && b_out)) {
+            const float s = da / (da - db);
+            out.add(in.p[j] + s * (in.p[k] - in.p[j]), in.t[j] + s * (in.t[k] - in.t[j]));
+        }
+        if (b_in && (a_in || a_out)) out.add(in.p[k], in.t[k]);
+    }
+    return out;
+}
+
 __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* pos, const float* uv, const float* N, const int32_t* tri,
                                                      const int32_t* tri_mesh, const int32_t* mesh_tex, RasterTri* out, uint32_t n_tris, uint2* bins, int tiles_x,
                                                      uint32_t* tile_count, uint32_t* big, uint32_t* big_count, float z_near, float z_scale) {
@@ -100,44 +131,28 @@ __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* 
         m4 M;
         memcpy(&M, F.M, 64);
         const f3 Nt = mul3(M, f3{N[3 * i], N[3 * i + 1], N[3 * i + 2]});       // rasterizer.cpp:112
-        f3 cpos[2][8];
-        f2 cuv[2][8];
+        ClipPoly poly;
+        poly.n = 0;
         for (int v = 0; v < 3; ++v) {
             const int vi = tri[3 * i + v];
-            cpos[0][v] = xform(F.M, f3{pos[3 * vi], pos[3 * vi + 1], pos[3 * vi + 2]});   // rasterizer.cpp:100
-            cuv[0][v] = f2{uv[2 * vi], uv[2 * vi + 1]};
+            poly.add(xform(F.M, f3{pos[3 * vi], pos[3 * vi + 1], pos[3 * vi + 2]}), f2{uv[2 * vi], uv[2 * vi + 1]});   // rasterizer.cpp:100
         }
-        if (!(dot(cpos[0][0], Nt) > 0)) {                                      // back-face cull, :113
-            int nin = 3, nout = 0, from = 0, to = 1;
-            for (int p = 0; p < 2; p++, from = 1 - from, to = 1 - to, nin = nout, nout = 0)   // :119-133
-                for (int v = 0; v < nin; v++) {
-                    const f3 A = cpos[from][v], B = cpos[from][(v + 1) % nin];
-                    const f2 Auv = cuv[from][v], Buv = cuv[from][(v + 1) % nin];
-                    const f3 pn = {F.frustum[p][0], F.frustum[p][1], F.frustum[p][2]};
-                    const float pw = F.frustum[p][3];
-                    const float t1 = dot(pn, A) - pw, t2 = dot(pn, B) - pw;
-                    if ((t1 < 0) && (t2 >= 0)) {
-                        const float f = t1 / (t1 - t2);
-                        cuv[to][nout] = Auv + f * (Buv - Auv); cpos[to][nout++] = A + f * (B - A);
-                        cuv[to][nout] = Buv; cpos[to][nout++] = B;
-                    } else if ((t1 >= 0) && (t2 >= 0)) { cuv[to][nout] = Buv; cpos[to][nout++] = B; }
-                    else if ((t1 >= 0) && (t2 < 0)) {
-                        const float f = t1 / (t1 - t2);
-                        cuv[to][nout] = Auv + f * (Buv - Auv); cpos[to][nout++] = A + f * (B - A);
-                    }
-                }
+        if (!(dot(poly.p[0], Nt) > 0)) {                                       // back-face cull, :113
+            for (int plane = 0; plane < 2; ++plane)
+                poly = clip_against(poly, f3{F.frustum[plane][0], F.frustum[plane][1], F.frustum[plane][2]}, F.frustum[plane][3]);
+            const int nin = poly.n;
             if (nin >= 3 && nin <= 5) {
                 T.level = (int)(gmax(0.0f, Nt.z) * 31);                        // :136
                 T.texture = texture;
                 float sx[5], sy[5], iz[5], uz[5], vz[5];
                 float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
                 for (int v = 0; v < nin; ++v) {
-                    const f3 p = cpos[from][v];
+                    const f3 p = poly.p[v];
                     sx[v] = ((p.x * W) / -p.z) + W / 2;                         // :140-141
                     sy[v] = ((p.y * W) / p.z) + H / 2;
                     iz[v] = 1.0f / p.z;                                        // :151
-                    uz[v] = cuv[from][v].x * iz[v];                            // :152-153
-                    vz[v] = cuv[from][v].y * iz[v];
+                    uz[v] = poly.t[v].x * iz[v];                               // :152-153
+                    vz[v] = poly.t[v].y * iz[v];
                     xmin = fminf(xmin, sx[v]); xmax = fmaxf(xmax, sx[v]);
                     ymin = fminf(ymin, sy[v]); ymax = fmaxf(ymax, sy[v]);
                 }
@@ -498,26 +513,30 @@ int raster_upload(RasterState& R, const mrt_mesh* meshes, int n_meshes, hipStrea
     return MRT_OK;
 }
 
-// Rasterizer::Init's frustum planes (rasterizer.cpp:31-41) for a W x H target
+// The five planes Rasterizer::Init sets up for a W x H target (rasterizer.cpp:31-41): the near plane z = -0.2 and
+// the four sides of the pyramid from the eye through the corners of the drawable pixel area
+// [0.5, W - 1.5] x [0.5, H - 1.5], left, top, right, bottom.  A side through the eye and the directions
+// a = (ax, ay, 1), b = (bx, by, 1) has the normal cross(a, b - a) = (-(by - ay), bx - ax, ax (by - ay) - (bx - ax) ay):
+// with a zero third component of b - a the general cross product reduces to this without a change in rounding.
 static void frustum_planes(int W, int H, f4 out[5]) {
-    const float C = -1.0f, x1 = 0.5f, x2 = W - 1.5f, y1 = 0.5f, y2 = H - 1.5f;
-    const f3 p0 = {0, 0, 0};
-    const f3 p1 = {((x1 - W / 2) * C) / W, ((y1 - H / 2) * C) / W, 1.0f};
-    const f3 p2 = {((x2 - W / 2) * C) / W, ((y1 - H / 2) * C) / W, 1.0f};
-    const f3 p3 = {((x2 - W / 2) * C) / W, ((y2 - H / 2) * C) / W, 1.0f};
-    const f3 p4 = {((x1 - W / 2) * C) / W, ((y2 - H / 2) * C) / W, 1.0f};
-    auto plane = [](f3 n) { return f4{n.x, n.y, n.z, 0}; };
+    const float lo_x = 0.5f, hi_x = W - 1.5f, lo_y = 0.5f, hi_y = H - 1.5f;
+    auto dir = [&](float px, float py) { return f2{((px - W / 2) * -1.0f) / W, ((py - H / 2) * -1.0f) / W}; };
+    const f2 corner[4] = {dir(lo_x, lo_y), dir(hi_x, lo_y), dir(hi_x, hi_y), dir(lo_x, hi_y)};
+    auto side = [](f2 a, f2 b) {
+        const float dx = b.x - a.x, dy = b.y - a.y;
+        const f3 n = normalize(f3{a.y * 0.0f - dy * 1.0f, 1.0f * dx - 0.0f * a.x, a.x * dy - dx * a.y});
+        return f4{n.x, n.y, n.z, 0};
+    };
     out[0] = {0, 0, -1, 0.2f};
-    out[1] = plane(normalize(cross(p1 - p0, p4 - p1)));
-    out[2] = plane(normalize(cross(p2 - p0, p1 - p2)));
-    out[3] = plane(normalize(cross(p3 - p0, p2 - p3)));
-    out[4] = plane(normalize(cross(p4 - p0, p3 - p4)));
+    for (int k = 0; k < 4; ++k) out[1 + k] = side(corner[k], corner[(k + 3) % 4]);     // from corner k back to the one before it
 }
 
+// device_out: fb, zbuf and tri_ids are DEVICE memory and are written by the kernels directly (covered pixels only for
+// fb, like a page-locked host frame); nothing is staged or copied back except the frame's pair count.
 int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const float cam16[16], uint32_t* fb, int pitch_px,
-                  float* zbuf, int32_t* tri_ids, hipStream_t stream, std::string& err) {
+                  float* zbuf, int32_t* tri_ids, bool device_out, hipStream_t stream, std::string& err) {
     const size_t npx = (size_t)W * H;
-    if (R.frame_px != npx) {
+    if (!device_out && R.frame_px != npx) {
         for (void* p : {(void*)R.d_fb, (void*)R.d_z, (void*)R.d_ids}) if (p) (void)hipFree(p);
         R.d_fb = nullptr; R.d_z = nullptr; R.d_ids = nullptr;
         RASTER_HIP(hipMalloc((void**)&R.d_fb, npx * 4));
@@ -589,8 +608,8 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
     // A frame in page-locked memory (mrt_host_alloc) is written by the kernel itself, covered pixels only; any
     // other frame comes back through page-locked staging and its covered pixels are merged in on the host
     // (the reference only plots covered pixels, so the rest must stay as the caller had it).
-    uint32_t* fb_direct = nullptr;
-    {
+    uint32_t* fb_direct = device_out ? fb : nullptr;
+    if (!device_out) {
         hipPointerAttribute_t at;
         if (hipPointerGetAttributes(&at, fb) == hipSuccess && at.type == hipMemoryTypeHost) {
             void* dp = nullptr;
@@ -598,7 +617,8 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
         }
         (void)hipGetLastError();
     }
-    const size_t need = npx * 4 + (tri_ids ? npx * 4 : 0) + (zbuf ? npx * 4 : 0) + 64;
+    const size_t out_px = device_out ? 0 : npx;        // pixels that come back through the staging buffer, per plane
+    const size_t need = out_px * 4 + (tri_ids ? out_px * 4 : 0) + (zbuf ? out_px * 4 : 0) + 64;
     if (R.h_stage_bytes < need) {
         if (R.h_stage) (void)hipHostFree(R.h_stage);
         R.h_stage = nullptr; R.h_stage_bytes = 0;
@@ -607,9 +627,9 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
     }
     unsigned char* stage = static_cast<unsigned char*>(R.h_stage);
     uint32_t* h_fb = reinterpret_cast<uint32_t*>(stage);
-    unsigned char* ids_stage = stage + npx * 4;
-    unsigned char* z_stage = ids_stage + (tri_ids ? npx * 4 : 0);
-    volatile uint32_t* h_pairs = reinterpret_cast<volatile uint32_t*>(z_stage + (zbuf ? npx * 4 : 0));   // the frame's pair count
+    unsigned char* ids_stage = stage + out_px * 4;
+    unsigned char* z_stage = ids_stage + (tri_ids ? out_px * 4 : 0);
+    volatile uint32_t* h_pairs = reinterpret_cast<volatile uint32_t*>(z_stage + (zbuf ? out_px * 4 : 0));   // the frame's pair count
     auto grow_pairs = [&](uint32_t n_pairs) -> int {
         if (n_pairs <= R.pair_capacity) return MRT_OK;
         if (R.d_pairs) (void)hipFree(R.d_pairs);
@@ -641,11 +661,11 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
         }
         hipLaunchKernelGGL(raster_tile, dim3(n_tiles), dim3(256), 0, stream, R.d_setup, R.d_tile_start, R.d_pairs, tiles_x, tx,
                            fb_direct ? fb_direct : R.d_fb, fb_direct ? pitch_px : W, fb_direct ? 1 : 0,
-                           zbuf ? R.d_z : nullptr, tri_ids ? R.d_ids : nullptr, W, H, capacity);
+                           zbuf ? (device_out ? zbuf : R.d_z) : nullptr, tri_ids ? (device_out ? tri_ids : R.d_ids) : nullptr, W, H, capacity);
         RASTER_HIP(hipGetLastError());
         if (!fb_direct) RASTER_HIP(hipMemcpyAsync(h_fb, R.d_fb, npx * 4, hipMemcpyDeviceToHost, stream));
-        if (tri_ids) RASTER_HIP(hipMemcpyAsync(ids_stage, R.d_ids, npx * 4, hipMemcpyDeviceToHost, stream));
-        if (zbuf) RASTER_HIP(hipMemcpyAsync(z_stage, R.d_z, npx * 4, hipMemcpyDeviceToHost, stream));
+        if (tri_ids && !device_out) RASTER_HIP(hipMemcpyAsync(ids_stage, R.d_ids, npx * 4, hipMemcpyDeviceToHost, stream));
+        if (zbuf && !device_out) RASTER_HIP(hipMemcpyAsync(z_stage, R.d_z, npx * 4, hipMemcpyDeviceToHost, stream));
         if (R.n_tris > 0) RASTER_HIP(hipMemcpyAsync((void*)h_pairs, R.d_total, 4, hipMemcpyDeviceToHost, stream));
         RASTER_HIP(hipStreamSynchronize(stream));      // also: h_mesh_tex may be rewritten by the next call only after its copy has been read
         if (*h_pairs <= R.pair_capacity) break;
@@ -659,6 +679,7 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
                 for (int x = 0; x < W; ++x) dst[x] = src[x] == kUncovered ? dst[x] : src[x];
             }
         }, 64);
+    if (device_out) return MRT_OK;
     if (tri_ids) parallel_for(npx, [&](size_t b, size_t e) { memcpy(tri_ids + b, ids_stage + 4 * b, (e - b) * 4); }, (size_t)1 << 18);
     if (zbuf) parallel_for(npx, [&](size_t b, size_t e) { memcpy(zbuf + b, z_stage + 4 * b, (e - b) * 4); }, (size_t)1 << 18);
     return MRT_OK;

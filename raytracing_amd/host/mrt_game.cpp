@@ -6,12 +6,19 @@
 //            [--mode packet|recursive|raster] [--pos x y z --lookat x y z]
 //            [--out frame.ppm] [--dump-scene out.mrts] [--device N]
 //            [--script "W*30 RIGHT*10 O*5 SPACE*1" --dt 0.016] [--no-render] [--pipeline]
+//            [--ranks N --rank R --nccl-id FILE [--block B] [--spp-grid G]]  |  [--rehearse-ranks N]
 //
 // --script replays Game::HandleInput (game.cpp:41-75) without a keyboard: each token holds one key for N
 // frames of length dt (W S A D R F move, LEFT RIGHT UP DOWN turn, O P move the light, SPACE switches
 // between ray tracer and rasterizer).  --no-render runs the script only and prints the final state.
 // --pipeline keeps the next frame in flight while the finished one is presented (two Surfaces,
 // mrt_render_submit / mrt_render_wait); ray-traced frames only.
+// --ranks N --rank R: one process per GPU (GPU R unless --device says otherwise).  The scene is replicated,
+// every process renders its interleaved share of the frame's tile rows (mrt_render_device_part) and the shares
+// are gathered on rank 0 with RCCL (mrt_gather_exchange); rank 0 reports and writes the frame.  The ranks find
+// each other through FILE: rank 0 writes the communicator's id there, the others wait for it.
+// --rehearse-ranks N: the same split and gather in ONE process on one GPU, a device copy standing in for the
+// transport; checks the assembled frame against the undivided one.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -20,11 +27,118 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#include <thread>
+
+#include "../../include/mrt_gather.h"
 #include "mrt_host.hpp"
 
 using namespace mrt_host;
 
+namespace {
+struct MultiOpts { int ranks = 1, rank = 0, block = 1, grid = 1, rehearse = 0; std::string id_file; };
+
+#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) throw std::runtime_error(std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+#define NCCL_OK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) throw std::runtime_error(std::string(#call) + ": " + ncclGetErrorString(r_)); } while (0)
+#define MRT_CHECK(ctx, call) do { int rc_ = (call); if (rc_ != MRT_OK) throw std::runtime_error(std::string(#call) + ": " + mrt_last_error(ctx)); } while (0)
+#define GATHER_OK(g, call) do { int rc_ = (call); if (rc_ != MRT_OK) throw std::runtime_error(std::string(#call) + ": " + mrt_gather_last_error(g)); } while (0)
+
+// rank 0 writes the id under a temporary name and renames it, so a reader never sees half a file
+ncclUniqueId share_id(const MultiOpts& m) {
+    ncclUniqueId id;
+    if (m.rank == 0) {
+        NCCL_OK(ncclGetUniqueId(&id));
+        const std::string tmp = m.id_file + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(&id, sizeof id, 1, f) != 1) throw std::runtime_error("cannot write " + tmp);
+        fclose(f);
+        if (rename(tmp.c_str(), m.id_file.c_str()) != 0) throw std::runtime_error("cannot rename to " + m.id_file);
+        return id;
+    }
+    for (int tries = 0; tries < 3000; ++tries) {          // up to five minutes
+        FILE* f = fopen(m.id_file.c_str(), "rb");
+        if (f) {
+            const bool ok = fread(&id, sizeof id, 1, f) == 1;
+            fclose(f);
+            if (ok) return id;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+    throw std::runtime_error("no communicator id appeared in " + m.id_file);
+}
+
+// One frame loop of the split render.  Real ranks: this process is rank m.rank of m.ranks.  Rehearsal: this
+// process plays every rank in turn on its one GPU.
+int run_split(const MultiOpts& m, mrt_host::Scene& scene, int W, int H, int frames, const std::string& mode, const mrt_host::Camera& camera,
+              int device, const std::string& out) {
+    using namespace mrt_host;
+    const bool rehearsal = m.rehearse > 0;
+    const int n = rehearsal ? m.rehearse : m.ranks, me = rehearsal ? 0 : m.rank;
+    const uint32_t flags = (mode == "recursive" ? MRT_MODE_RECURSIVE : MRT_MODE_PACKET) | MRT_SPP_GRID(m.grid);
+    HIP_OK(hipSetDevice(device >= 0 ? device : (rehearsal ? 0 : m.rank)));
+    ncclComm_t comm = nullptr;
+    if (!rehearsal) NCCL_OK(ncclCommInitRank(&comm, n, share_id(m), me));
+    Surface screen(W, H);
+    Raytracer raytracer;
+    raytracer.Init(&screen, -1);
+    raytracer.BuildBVH(scene);
+    mrt_ctx* ctx = raytracer.Context();
+    mrt_gather* g = nullptr;
+    if (mrt_gather_create(W, H, me, n, m.block, &g) != MRT_OK) throw std::runtime_error(std::string("mrt_gather_create: ") + mrt_gather_last_error(nullptr));
+    hipStream_t stream;
+    HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    const int my_rows = me == 0 ? H : mrt_gather_share_rows(g, me);
+    uint32_t *fb = nullptr, *packed = nullptr;
+    HIP_OK(hipMalloc((void**)&fb, (size_t)(my_rows > 0 ? my_rows : 8) * W * 4));
+    if (rehearsal) HIP_OK(hipMalloc((void**)&packed, (size_t)H * W * 4));
+    double total_ms = 0, best_ms = 1e30;
+    for (int f = 0; f < frames; ++f) {
+        HIP_OK(hipStreamSynchronize(stream));
+        const auto t0 = std::chrono::steady_clock::now();
+        MRT_CHECK(ctx, mrt_render_device_part(ctx, camera.transform, flags, me, n, m.block, me != 0, fb, W, nullptr, stream));
+        if (rehearsal) {
+            for (int r = 1; r < n; ++r) {
+                if (mrt_gather_share_rows(g, r) == 0) continue;
+                MRT_CHECK(ctx, mrt_render_device_part(ctx, camera.transform, flags, r, n, m.block, 1, packed, W, nullptr, stream));
+                GATHER_OK(g, mrt_gather_stage_local(g, r, packed, stream));
+                GATHER_OK(g, mrt_gather_scatter(g, r, fb, W, stream));
+            }
+        } else {
+            GATHER_OK(g, mrt_gather_exchange(g, comm, fb, W, stream));
+        }
+        if (me == 0) HIP_OK(hipMemcpyAsync(screen.GetBuffer(), fb, (size_t)H * W * 4, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (f > 0 || frames == 1) { total_ms += ms; best_ms = ms < best_ms ? ms : best_ms; }
+    }
+    int rc = 0;
+    if (me == 0) {
+        const int counted = frames > 1 ? frames - 1 : 1;
+        printf("%s of %d: Frametime : %f ms (best %f), FPS : %.1f  [%dx%d, %d x %d samples, %s, tile rows dealt in blocks of %d]\n",
+               rehearsal ? "rehearsal" : "rank 0", n, total_ms / counted, best_ms, 1000.0 * counted / total_ms, W, H, m.grid, m.grid, mode.c_str(), m.block);
+        if (rehearsal) {
+            std::vector<uint32_t> whole((size_t)W * H);
+            MRT_CHECK(ctx, mrt_render_device(ctx, camera.transform, flags, 0, H, packed, W, nullptr, stream));
+            HIP_OK(hipMemcpyAsync(whole.data(), packed, whole.size() * 4, hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipStreamSynchronize(stream));
+            const bool same = !memcmp(whole.data(), screen.GetBuffer(), whole.size() * 4);
+            printf("frame assembled from %d shares %s the undivided frame\n", n, same ? "is identical to" : "DIFFERS from");
+            if (!same) rc = 3;
+        }
+        if (!out.empty() && screen.SavePPM(out)) printf("wrote %s\n", out.c_str());
+    }
+    if (comm) NCCL_OK(ncclCommDestroy(comm));
+    mrt_gather_destroy(g);
+    (void)hipFree(fb);
+    if (packed) (void)hipFree(packed);
+    (void)hipStreamDestroy(stream);
+    return rc;
+}
+}  // namespace
+
 int main(int argc, char** argv) {
+    MultiOpts multi;
     std::string scene_file = "assets/maze.obj", mode = "packet", out, dump, script;
     float dt = 0.016f;
     bool no_render = false, pipeline = false;
@@ -44,6 +158,12 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--dt")) { need(1); dt = (float)atof(argv[++i]); }
         else if (!strcmp(argv[i], "--no-render")) no_render = true;
         else if (!strcmp(argv[i], "--pipeline")) pipeline = true;
+        else if (!strcmp(argv[i], "--ranks")) { need(1); multi.ranks = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--rank")) { need(1); multi.rank = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--nccl-id")) { need(1); multi.id_file = argv[++i]; }
+        else if (!strcmp(argv[i], "--block")) { need(1); multi.block = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--spp-grid")) { need(1); multi.grid = atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--rehearse-ranks")) { need(1); multi.rehearse = atoi(argv[++i]); }
         else if (!strcmp(argv[i], "--pos")) { need(3); pos = {(float)atof(argv[i + 1]), (float)atof(argv[i + 2]), (float)atof(argv[i + 3])}; i += 3; have_pose = true; }
         else if (!strcmp(argv[i], "--lookat")) { need(3); target = {(float)atof(argv[i + 1]), (float)atof(argv[i + 2]), (float)atof(argv[i + 3])}; i += 3; have_pose = true; }
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
@@ -70,6 +190,15 @@ int main(int argc, char** argv) {
         }
         if (!keys.empty()) frames = (int)keys.size();
 
+        if (multi.ranks > 1 || multi.rehearse > 0) {
+            if (multi.rehearse <= 0 && (multi.id_file.empty() || multi.rank < 0 || multi.rank >= multi.ranks)) {
+                fprintf(stderr, "--ranks needs --rank R (0 <= R < N) and --nccl-id FILE\n");
+                return 2;
+            }
+            Camera cam;
+            if (have_pose) { cam.SetPosition(pos); cam.LookAt(target); }
+            return run_split(multi, scene, W, H, frames, mode, cam, device, out);
+        }
         Surface screen(W, H);                                   // template.cpp:98
         Surface screen2(pipeline ? W : 8, pipeline ? H : 8);    // second frame of the pipelined loop
         int prev_ticket = -1;

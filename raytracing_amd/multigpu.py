@@ -13,7 +13,92 @@ tile rows are dealt to the ranks in blocks (``part_row_index``), every rank othe
 its share packed into a small buffer and sends that one buffer, and rank 0 -- which renders its own
 share in place -- scatters the received rows to their places (``PartGather``).
 """
+import ctypes as C
+import os
+
 import numpy as np
+
+GATHER_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmrt_gather.so")
+GATHER_SYMBOLS = ("mrt_gather_create", "mrt_gather_destroy", "mrt_gather_last_error", "mrt_gather_share_rows",
+                  "mrt_gather_frame_row", "mrt_gather_exchange", "mrt_gather_staging", "mrt_gather_stage_local", "mrt_gather_scatter")
+_glib = None
+
+
+def gather_lib():
+    """libmrt_gather.so: the native (C++ / RCCL) form of the exchange, declared in include/mrt_gather.h."""
+    global _glib
+    if _glib is None:
+        if not os.path.exists(GATHER_LIB_PATH):
+            raise RuntimeError("%s is missing: build it with `make -C raytracing_amd/csrc`" % GATHER_LIB_PATH)
+        from . import binding
+        binding._preload_torch_hip_runtime()
+        L = C.CDLL(GATHER_LIB_PATH)
+        vp, i32 = C.c_void_p, C.c_int
+        L.mrt_gather_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
+        L.mrt_gather_destroy.argtypes = [vp]
+        L.mrt_gather_destroy.restype = None
+        L.mrt_gather_last_error.argtypes = [vp]
+        L.mrt_gather_last_error.restype = C.c_char_p
+        L.mrt_gather_share_rows.argtypes = [vp, i32]
+        L.mrt_gather_frame_row.argtypes = [i32, i32, i32, i32, i32]
+        L.mrt_gather_exchange.argtypes = [vp, vp, vp, i32, vp]
+        L.mrt_gather_staging.argtypes = [vp, i32]
+        L.mrt_gather_staging.restype = vp
+        L.mrt_gather_scatter.argtypes = [vp, i32, vp, i32, vp]
+        L.mrt_gather_stage_local.argtypes = [vp, i32, vp, vp]
+        _glib = L
+    return _glib
+
+
+def native_frame_rows(height, world, rank, block=1):
+    """part_row_index as the native library computes it (mrt_gather_frame_row), for cross-checks."""
+    L = gather_lib()
+    out = []
+    k = 0
+    while True:
+        r = L.mrt_gather_frame_row(height, world, block, rank, k)
+        if r < 0:
+            break
+        out.append(r)
+        k += 1
+    return np.asarray(out, np.int64)
+
+
+class NativeGather:
+    """Rank 0's side of the native exchange without a communicator: receive buffers and the row-scatter kernel
+    (mrt_gather_staging / mrt_gather_scatter).  With an ncclComm_t, mrt_gather_exchange does both sides."""
+
+    def __init__(self, width, height, rank, world, block=1):
+        self.L = gather_lib()
+        h = C.c_void_p()
+        rc = self.L.mrt_gather_create(width, height, rank, world, block, C.byref(h))
+        if rc != 0:
+            raise RuntimeError("mrt_gather_create failed (%d): %s" % (rc, self.L.mrt_gather_last_error(None).decode()))
+        self.h, self.world = h, world
+
+    def share_rows(self, rank):
+        return self.L.mrt_gather_share_rows(self.h, rank)
+
+    def staging(self, peer):
+        return self.L.mrt_gather_staging(self.h, peer)
+
+    def stage_local(self, peer, packed_ptr, stream=None):
+        rc = self.L.mrt_gather_stage_local(self.h, peer, C.c_void_p(packed_ptr), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise RuntimeError("mrt_gather_stage_local failed (%d): %s" % (rc, self.L.mrt_gather_last_error(self.h).decode()))
+
+    def scatter(self, peer, frame_ptr, pitch, stream=None):
+        rc = self.L.mrt_gather_scatter(self.h, peer, C.c_void_p(frame_ptr), pitch, C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise RuntimeError("mrt_gather_scatter failed (%d): %s" % (rc, self.L.mrt_gather_last_error(self.h).decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mrt_gather_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
 
 
 def band_rows(height, world, rank):

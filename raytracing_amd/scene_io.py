@@ -120,3 +120,10 @@ def soup_scene(n_tris, seed=12345, texture=None):
             "tri": np.arange(n_tris * 3, dtype=np.int32).reshape(-1, 3), "texture": 0,
             "bounds": np.concatenate([flat.min(0), flat.max(0)]).astype(f), "refl": 0.0, "refr": 0.0, "rindex": 1.0}
     return {"textures": [texture], "meshes": [mesh]}
+
+
+def large_scene(maze_scene, n_tris=1000000):
+    """The large-scene and rasterizer configurations' input: the triangle soup above carrying the default scene's
+    512 x 512 grass texture (the second texture of the maze: assets/textures/grass.bin)."""
+    grass = next(t for t in maze_scene["textures"] if int(t["w"]) == 512 and int(t["h"]) == 512)
+    return soup_scene(n_tris, texture={"w": int(grass["w"]), "h": int(grass["h"]), "idx": grass["idx"], "pal": grass["pal"]})

@@ -37,6 +37,14 @@ def maze_scene():
 
 
 @pytest.fixture(scope="session")
+def full_size():
+    """Whole-frame answers of the oracle at the benchmark configurations' full sizes (made by make_full_size_goldens.py)."""
+    import json
+    with open(os.path.join(GOLDEN, "full_size.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
 def maze_oracle(maze_scene):
     import oracle_lib
     o = oracle_lib.Oracle()

@@ -56,6 +56,7 @@ def lib():
         L.ora_mat4_inverse.argtypes = [vp, vp]
         L.ora_view_plane.argtypes = [vp, i32, i32, vp]
         L.ora_set_threads.argtypes = [vp, i32]
+        L.ora_set_threads_pinned.argtypes = [vp, i32]
         L.ora_render.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
         L.ora_trace_ray.argtypes = [vp, vp, vp, f32, i32, vp, vp]
         L.ora_trace_ray_brute.argtypes = [vp, vp, vp, f32, vp, vp]
@@ -63,6 +64,7 @@ def lib():
         L.ora_trace_rays.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
         L.ora_gen_ray.argtypes = [vp, i32, i32, i32, i32, vp, vp]
         L.ora_raster_render.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+        L.ora_raster_work.argtypes = [vp, vp]
         _lib = L
     return _lib
 
@@ -73,7 +75,7 @@ def _p(a):
 
 IDENTITY = np.eye(4, dtype=np.float32).reshape(16)
 COUNTER_NAMES = ("packet_box", "packet_tri", "packet_nodes", "packet_leaves", "scalar_box", "scalar_tri",
-                 "scalar_nodes", "scalar_rays", "primary_rays", "shadow_rays", "secondary_rays")
+                 "scalar_nodes", "scalar_rays", "primary_rays", "shadow_rays", "secondary_rays", "packet_trifetch")
 
 
 def lookat(pos, target):
@@ -169,8 +171,13 @@ class Oracle:
         return int(self.L.ora_nodehash(self.h))
 
     # ---- rendering ----
-    def set_threads(self, n):
+    def set_threads(self, n, pinned=False):
+        """Worker threads of the tile pool; pinned=True keeps each on its own CPU (distinct physical cores first) and
+        returns how many distinct cores they occupy (0: pinning refused by the system)."""
+        if pinned:
+            return self.L.ora_set_threads_pinned(self.h, n)
         self.L.ora_set_threads(self.h, n)
+        return 0
 
     def render(self, cam, W, H, mode=0, spp_grid=1, rows=None, want_ids=True, want_tuv=False, want_counters=False):
         cam = np.ascontiguousarray(cam, np.float32).reshape(16)
@@ -188,7 +195,7 @@ class Oracle:
             out["counters"] = dict(zip(COUNTER_NAMES, (int(x) for x in ctr)))
         return out
 
-    def render_band(self, cam, W, H, y0, y1, mode=0, spp_grid=1):
+    def render_band(self, cam, W, H, y0, y1, mode=0, spp_grid=1, want_counters=False):
         """Rows [y0, y1) of the frame only, without allocating the whole frame (full-size configurations):
         returns the band's pixels (y1-y0, W) and hit ids ((y1-y0)*g, W*g)."""
         cam = np.ascontiguousarray(cam, np.float32).reshape(16)
@@ -198,9 +205,12 @@ class Oracle:
         # the library indexes both arrays by frame row; hand it the address frame row 0 would have
         fb0 = C.c_void_p(fb.ctypes.data - y0 * W * 4)
         ids0 = C.c_void_p(ids.ctypes.data - y0 * g * W * g * 4)
-        rc = self.L.ora_render(self.h, _p(cam), W, H, mode, spp_grid, y0, y1, fb0, W, ids0, None, None)
+        ctr = np.zeros(len(COUNTER_NAMES), np.uint64) if want_counters else None
+        rc = self.L.ora_render(self.h, _p(cam), W, H, mode, spp_grid, y0, y1, fb0, W, ids0, None, _p(ctr))
         if rc != 0:
             raise RuntimeError("ora_render failed")
+        if want_counters:
+            return fb, ids, dict(zip(COUNTER_NAMES, (int(x) for x in ctr)))
         return fb, ids
 
     def trace_ray(self, O, D, tmax=1e8, kind=0):
@@ -251,12 +261,23 @@ class Oracle:
         z = np.zeros((H, W), np.float32)
         ids = np.full((H, W), -1, np.int32) if want_ids else None
         self.L.ora_raster_render(self.h, _p(np.ascontiguousarray(cam, np.float32)), W, H, _p(fb), _p(z), _p(ids))
-        return {"fb": fb, "z": z, "ids": ids}
+        work = np.zeros(3, np.uint64)
+        self.L.ora_raster_work(self.h, _p(work))
+        return {"fb": fb, "z": z, "ids": ids, "fragments": int(work[0]), "fragments_drawn": int(work[1]), "triangles_drawn": int(work[2])}
 
 
 def fbhash(fb):
     fb = np.ascontiguousarray(fb, np.uint32)
     return int(lib().ora_fbhash(_p(fb), fb.size))
+
+
+def fbhash_continue(h0, fb):
+    """fbhash of a frame built up from its row bands, top to bottom: h = fbhash_continue(h, band)."""
+    fb = np.ascontiguousarray(fb, np.uint32)
+    L = lib()
+    L.ora_fbhash_from.restype = C.c_uint64
+    L.ora_fbhash_from.argtypes = [C.c_uint64, C.c_void_p, C.c_int64]
+    return int(L.ora_fbhash_from(h0, _p(fb), fb.size))
 
 
 def idsum(ids):

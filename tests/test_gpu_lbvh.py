@@ -1,6 +1,7 @@
 """The GPU-built linear BVH (mrt_scene_upload_lbvh) is an alternative acceleration structure, not the
-reference's tree: nearest distances must be those of the reference tree bit for bit, triangle IDs may
-only differ where two triangles are hit at exactly the same distance."""
+reference's tree: nearest distances must be those the CPU ORACLE finds on the reference's tree, bit for bit
+(packet operator, single-ray operator with its root gate, whole frames), triangle IDs may only differ where
+two triangles are hit at exactly the same distance."""
 import numpy as np
 import pytest
 
@@ -33,29 +34,39 @@ def test_lbvh_gives_the_same_nearest_hits(maze_scene, scene_name):
     ref.build_bvh(scene)
     alt = Raytracer(W, H, device=0)
     alt.build_bvh(scene, lbvh=True)
+    ora = oracle_lib.Oracle()
+    ora.add_scene(scene)
+    ora.build_bvh()
+    ora.set_threads(8)
     for pose in POSES[:4]:
         cam = pose_cam(pose)
         O, D, rD = _primary_packets(np.asarray(getattr(cam, "transform", cam), np.float32), W, H)
         t0 = np.full(O.shape[:2], 1e8, np.float32)
         ta, ia, ua, va = ref.trace_packets(O, D, rD, t0)
         tb, ib, ub, vb = alt.trace_packets(O, D, rD, t0)
-        assert np.array_equal(ta.view(np.uint32), tb.view(np.uint32)), "nearest distances differ on %d rays" % int((ta != tb).sum())
-        assert np.array_equal(ia >= 0, ib >= 0)
-        differ = ia != ib
+        to, io, uo, vo = ora.trace_packets(O, D, rD, t0)
+        assert np.array_equal(to.view(np.uint32), tb.view(np.uint32)), "nearest distances differ from the oracle's on %d rays" % int((to != tb).sum())
+        assert np.array_equal(ta.view(np.uint32), to.view(np.uint32)) and np.array_equal(ia, io)      # the reference tree on the GPU: ids too
+        assert np.array_equal(io >= 0, ib >= 0)
+        differ = io != ib
         assert differ.mean() <= 0.001            # only exact ties may name another triangle
+        same = ~differ & (io >= 0)
+        assert np.array_equal(uo.view(np.uint32)[same], ub.view(np.uint32)[same]) and np.array_equal(vo.view(np.uint32)[same], vb.view(np.uint32)[same])
         # single rays through BVH::Traverse semantics (root gate and true divisions): same distances too
         n = O.shape[0] * 64
         ta1, ia1, _, _ = ref.trace_rays(O.reshape(n, 3), D.reshape(n, 3), np.full(n, 1e8, np.float32))
         tb1, ib1, _, _ = alt.trace_rays(O.reshape(n, 3), D.reshape(n, 3), np.full(n, 1e8, np.float32))
-        assert np.array_equal(ta1.view(np.uint32), tb1.view(np.uint32)) and (ia1 != ib1).mean() <= 0.001
+        to1, io1, _, _ = ora.trace_rays(O.reshape(n, 3), D.reshape(n, 3), np.full(n, 1e8, np.float32))
+        assert np.array_equal(to1.view(np.uint32), tb1.view(np.uint32)) and (io1 != ib1).mean() <= 0.001
+        assert np.array_equal(ta1.view(np.uint32), to1.view(np.uint32)) and np.array_equal(ia1, io1)
         # whole frames, both shaders: pixels equal wherever the triangles agree
         for mode in (MODE_PACKET, MODE_RECURSIVE):
-            fa, ida = ref.render(cam, mode=mode)
             fb, idb = alt.render(cam, mode=mode)
-            same = ida == idb
+            want = ora.render(np.asarray(getattr(cam, "transform", cam), np.float32), W, H, mode=mode)
+            same = want["ids"] == idb
             assert same.mean() >= 0.999
             if mode == MODE_PACKET:
-                assert np.array_equal(fa[same], fb[same])
+                assert np.array_equal(want["fb"][same], fb[same])
     ref.close(); alt.close()
 
 

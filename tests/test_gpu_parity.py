@@ -79,9 +79,10 @@ def test_full_hd_both_modes_match_oracle(maze_scene, maze_oracle):
     """The headline configuration's size: 1920x1080, packet and recursive."""
     rt = Raytracer(1920, 1080, device=0)
     rt.build_bvh(maze_scene)
-    cam = pose_cam(POSES[1])
-    _check_frame(rt, maze_oracle, cam, 1920, 1080, MODE_PACKET)
-    _check_frame(rt, maze_oracle, cam, 1920, 1080, MODE_RECURSIVE, exact_pixels=False)
+    for pose in (POSES[1], POSES[0]):       # POSES[0] is the default camera, the benchmark's pose
+        cam = pose_cam(pose)
+        _check_frame(rt, maze_oracle, cam, 1920, 1080, MODE_PACKET)
+        _check_frame(rt, maze_oracle, cam, 1920, 1080, MODE_RECURSIVE, exact_pixels=False)
     rt.close()
 
 
@@ -284,10 +285,46 @@ def test_interleaved_shares_on_device_equal_full_frame(maze_scene, mode, grid):
     rt.close()
 
 
-def test_8k_16spp_frame_rows_match_oracle(maze_scene, maze_oracle):
+@pytest.mark.parametrize("world,block,pitch_extra", [(2, 1, 0), (3, 4, 0), (8, 2, 8), (4, 40, 3)])
+def test_native_gather_scatter_reassembles_the_frame(maze_scene, world, block, pitch_extra):
+    """The native exchange (libmrt_gather.so) without its transport: every share but rank 0's is rendered packed,
+    copied into rank 0's receive buffer for that peer and put in place by the scatter kernel; the frame must equal
+    the undivided one.  Only ncclSend / ncclRecv themselves are not exercised (one GPU here)."""
+    import torch
+    from raytracing_amd.multigpu import NativeGather
+    W, H = 256, 264
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(maze_scene)
+    cam = pose_cam(POSES[1])
+    full, _ = rt.render(cam, mode=MODE_RECURSIVE)
+    stream = torch.cuda.current_stream().cuda_stream
+    pitch = W + pitch_extra
+    frame = torch.zeros((H, pitch), dtype=torch.int32, device="cuda:0")
+    g = NativeGather(W, H, 0, world, block)
+    rt.render_device_part(cam, frame.data_ptr(), pitch, 0, world, block, compact=False, mode=MODE_RECURSIVE, stream=stream)
+    for r in range(1, world):
+        n = g.share_rows(r)
+        assert n == rt.L.mrt_part_rows(H, r, world, block)
+        if n == 0:
+            assert not g.staging(r)
+            continue
+        packed = torch.zeros((n, W), dtype=torch.int32, device="cuda:0")
+        rt.render_device_part(cam, packed.data_ptr(), W, r, world, block, compact=True, mode=MODE_RECURSIVE, stream=stream)
+        g.stage_local(r, packed.data_ptr(), stream)
+        g.scatter(r, frame.data_ptr(), pitch, stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame[:, :W].cpu().numpy().view(np.uint32), full)
+    if pitch_extra:
+        assert int(frame[:, W:].abs().sum()) == 0
+    g.close()
+    rt.close()
+
+
+def test_8k_16spp_frame_rows_match_oracle(maze_scene, maze_oracle, full_size):
     """The multi-GPU configuration at its full size (7680x4320, 4x4 sample grid = 530,841,600 primary
-    rays): the whole frame is rendered once, and four 8-row strips of it -- first, last, and two through
-    the middle of the scene -- are checked against the oracle, pixels and hit ids of all 16 samples."""
+    rays): the whole frame is rendered once and its hash compared with the hash the oracle produced for this
+    frame offline (tests/golden/full_size.json); 34 of its 540 8-row strips -- first, last, and 32 drawn at
+    random -- are also compared with the oracle here, pixels and, for six of them, the hit ids of all 16 samples."""
     import torch
     W, H, g = 7680, 4320, 4
     rt = Raytracer(W, H, device=0)
@@ -299,28 +336,36 @@ def test_8k_16spp_frame_rows_match_oracle(maze_scene, maze_oracle):
     torch.cuda.synchronize()
     counts = rt.ray_counts()
     assert counts["primary"] == W * H * g * g and counts["shadow"] == counts["primary_hits"]
+    gold = full_size["c4_maze_8k_16spp_packet"]
+    assert counts["primary_hits"] == gold["primary_hits"] == gold["counters"]["shadow_rays"]
+    whole = fb.cpu().numpy().view(np.uint32)
+    assert "%016x" % oracle_lib.fbhash(whole) == gold["fbhash"], "the 8K / 16 spp frame differs from the oracle's"
     n_rows = H // 8
     strip = torch.zeros((8, W), dtype=torch.int32, device="cuda:0")
     ids = torch.zeros((8 * g, W * g), dtype=torch.int32, device="cuda:0")
-    for R in (0, 231, 300, n_rows - 1):
+    maze_oracle.set_threads(16)
+    rows = [0, n_rows - 1] + sorted(np.random.RandomState(5).choice(np.arange(1, n_rows - 1), 32, replace=False).tolist())
+    for j, R in enumerate(rows):
         ref_fb, ref_ids = maze_oracle.render_band(cam, W, H, 8 * R, 8 * R + 8, mode=MODE_PACKET, spp_grid=g)
-        assert np.array_equal(fb[8 * R:8 * R + 8].cpu().numpy().view(np.uint32), ref_fb), "tile row %d" % R
-        # the same strip as a packed share (one tile row per share), with the hit ids of its samples
-        rt.render_device_part(cam, strip.data_ptr(), W, R, n_rows, 1, compact=True, mode=MODE_PACKET, spp_grid=g,
-                              ids_ptr=ids.data_ptr(), stream=stream)
-        torch.cuda.synchronize()
-        assert np.array_equal(strip.cpu().numpy().view(np.uint32), ref_fb)
-        assert np.array_equal(ids.cpu().numpy(), ref_ids)
+        assert np.array_equal(whole[8 * R:8 * R + 8], ref_fb), "tile row %d" % R
+        if j % 6 == 0:
+            # the same strip as a packed share (one tile row per share), with the hit ids of its samples
+            rt.render_device_part(cam, strip.data_ptr(), W, R, n_rows, 1, compact=True, mode=MODE_PACKET, spp_grid=g,
+                                  ids_ptr=ids.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(strip.cpu().numpy().view(np.uint32), ref_fb)
+            assert np.array_equal(ids.cpu().numpy(), ref_ids)
     rt.close()
 
 
-def test_million_triangle_scene_4k_rows_match_oracle():
-    """The large-scene and the rasterizer configurations at their full size: 1,000,000-triangle soup,
-    3840x2160, scene in global memory.  BVH arrays identical to the oracle's; strips of the packet frame and of the
-    recursive frame (hit ids and pixels) equal the oracle's."""
+def test_million_triangle_scene_4k_rows_match_oracle(maze_scene, full_size):
+    """The large-scene and the rasterizer configurations at their full size: 1,000,000-triangle soup with the grass
+    texture, 3840x2160, scene in global memory.  BVH arrays identical to the oracle's; the whole packet frame (hash and
+    hit-id checksum) and the whole recursive frame equal what the oracle produced offline (tests/golden/full_size.json);
+    34 strips of each are also compared with the oracle here (hit ids and pixels)."""
     import torch
     W, H = 3840, 2160
-    scene = scene_io.soup_scene(1000000)
+    scene = scene_io.large_scene(maze_scene)
     ora = oracle_lib.Oracle()
     ora.add_scene(scene)
     ora.build_bvh()
@@ -338,8 +383,18 @@ def test_million_triangle_scene_4k_rows_match_oracle():
     n_rows = H // 8
     strip = torch.zeros((8, W), dtype=torch.int32, device="cuda:0")
     ids = torch.zeros((8, W), dtype=torch.int32, device="cuda:0")
-    for mode in (MODE_PACKET, MODE_RECURSIVE):
-        for R in (3, 135, 200, n_rows - 2):
+    ora.set_threads(16)
+    whole = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
+    whole_ids = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
+    for mode, key in ((MODE_PACKET, "c3_soup1m_4k_packet"), (MODE_RECURSIVE, "c3_soup1m_4k_recursive")):
+        rt.render_device(cam, whole.data_ptr(), W, mode=mode, ids_ptr=whole_ids.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        gold = full_size[key]
+        assert oracle_lib.idsum(whole_ids.cpu().numpy()) == gold["idsum"] and int((whole_ids >= 0).sum()) == gold["primary_hits"]
+        if mode == MODE_PACKET:
+            assert "%016x" % oracle_lib.fbhash(whole.cpu().numpy().view(np.uint32)) == gold["fbhash"]
+        rows = [0, n_rows - 1] + sorted(np.random.RandomState(7 + mode).choice(np.arange(1, n_rows - 1), 32, replace=False).tolist())
+        for R in rows:
             ref_fb, ref_ids = ora.render_band(cam, W, H, 8 * R, 8 * R + 8, mode=mode)
             rt.render_device_part(cam, strip.data_ptr(), W, R, n_rows, 1, compact=True, mode=mode,
                                   ids_ptr=ids.data_ptr(), stream=stream)
@@ -531,6 +586,21 @@ def test_cpp_host_driver_renders_reference_frame(tmp_path, known, loop):
     rt.close()
     assert "%016x" % oracle_lib.fbhash(fb) == known["packet_frames"][1]["fbhash"]
     assert np.array_equal((rgb[..., 0] << 16) | (rgb[..., 1] << 8) | rgb[..., 2], fb & 0xFFFFFF)
+
+
+@pytest.mark.parametrize("args", [["--rehearse-ranks", "3", "--size", "512", "264", "--mode", "recursive", "--block", "2"],
+                                  ["--rehearse-ranks", "8", "--size", "960", "544", "--mode", "packet", "--spp-grid", "4"]],
+                         ids=["3 ranks recursive", "8 ranks 16 spp"])
+def test_cpp_host_driver_split_render_with_native_gather(args):
+    """mrt_game playing every rank of the multi-GPU split in one process: shares rendered packed, moved into rank 0's
+    receive buffers and scattered by libmrt_gather.so; the driver itself compares with the undivided frame."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "raytracing_amd", "host", "mrt_game")
+    r = subprocess.run([exe, "--scene", os.path.join(ROOT, "tests", "golden", "maze.mrts"), "--frames", "3", "--pos", "6", "3", "12",
+                        "--lookat", "0", "0", "0"] + args, capture_output=True, text=True)
+    assert r.returncode == 0 and "is identical to the undivided frame" in r.stdout, r.stdout[-400:] + r.stderr[-400:]
 
 
 def test_random_pose_campaign():

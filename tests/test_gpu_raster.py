@@ -116,3 +116,29 @@ def test_raster_pair_buffer_grows_between_frames():
         for a, b in zip(got[i], want):
             assert np.array_equal(a, b), "frame %d differs from a fresh context's" % i
     assert (got[2][2] >= 0).mean() > 0.9 and (got[0][2] >= 0).mean() < 0.5
+
+
+def test_raster_into_device_memory_equals_host_frame(maze_scene):
+    """mrt_raster_render_device: frame, 1/z and triangle ids written into device memory (frame with a pitch wider
+    than the image, covered pixels only) equal what mrt_raster_render hands back on the host; also on a context
+    whose first rasterizer call this is (the triangle-list buffer is sized inside the call)."""
+    import torch
+    W, H = 800, 600
+    cam = pose_cam(POSES[1])
+    stream = torch.cuda.current_stream().cuda_stream
+    for first_call_is_device in (True, False):
+        rt = Raytracer(W, H, device=0)
+        rt.build_bvh(maze_scene)
+        if not first_call_is_device:
+            rt.raster(cam)
+        fb = torch.full((H, W + 32), 0x00123456, dtype=torch.int32, device="cuda:0")
+        z = torch.full((H, W), 7.0, dtype=torch.float32, device="cuda:0")
+        ids = torch.full((H, W), -9, dtype=torch.int32, device="cuda:0")
+        rt.raster_device(cam, fb.data_ptr(), W + 32, z_ptr=z.data_ptr(), ids_ptr=ids.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        want_fb, want_z, want_ids = rt.raster(cam, fb=np.full((H, W), 0x00123456, np.uint32))
+        got = fb.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got[:, :W], want_fb) and (got[:, W:] == 0x00123456).all()
+        assert np.array_equal(ids.cpu().numpy(), want_ids)
+        assert np.array_equal(z.cpu().numpy().view(np.uint32), want_z.view(np.uint32))
+        rt.close()

@@ -208,3 +208,69 @@ def test_bench_workload_multi_rank_logic(tmp_path, world, split, maze_oracle):
     ref = maze_oracle.render(oracle_lib.lookat((6, 3, 12), (0, 0, 0)), W, H, mode=0, want_ids=False)["fb"]
     for f in got:
         assert np.array_equal(f, ref)
+
+
+def test_native_gather_exports_and_row_map_match_the_python_split():
+    """libmrt_gather.so exports what include/mrt_gather.h declares, and its frame-row map (the one its scatter kernel
+    uses) equals part_row_index, ragged cycles and empty shares included."""
+    import ctypes
+    import re
+    from raytracing_amd import multigpu
+    with open(os.path.join(ROOT, "include", "mrt_gather.h")) as f:
+        declared = set(re.findall(r"\b(mrt_gather_[a-z_0-9]+)\s*\(", f.read()))
+    assert declared == set(multigpu.GATHER_SYMBOLS), declared ^ set(multigpu.GATHER_SYMBOLS)
+    L = ctypes.CDLL(multigpu.GATHER_LIB_PATH)
+    for s in declared:
+        assert hasattr(L, s), s
+    for h, world, block in ((264, 2, 1), (264, 3, 4), (264, 8, 2), (264, 4, 40), (4320, 8, 1), (8, 3, 1), (1080, 7, 5)):
+        seen = []
+        for r in range(world):
+            rows = multigpu.native_frame_rows(h, world, r, block)
+            assert np.array_equal(rows, multigpu.part_row_index(h, world, r, block)), (h, world, block, r)
+            seen.append(rows)
+        assert np.array_equal(np.sort(np.concatenate(seen)), np.arange(h))
+    G = multigpu.gather_lib()
+    assert G.mrt_gather_frame_row(264, 2, 1, 2, 0) < 0 and G.mrt_gather_frame_row(260, 2, 1, 0, 0) < 0
+    assert G.mrt_gather_frame_row(264, 2, 1, 0, 136) < 0          # past the share's last row
+
+
+def _native_map_worker(rank, world, port, W, H, block, out_path):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from raytracing_amd import multigpu
+    # the "frame": every pixel names its own row and column, so a misplaced row shows
+    full = (np.arange(H, dtype=np.int32)[:, None] * 100000 + np.arange(W, dtype=np.int32)[None, :])
+    mine = multigpu.native_frame_rows(H, world, rank, block)
+    if rank == 0:
+        frame = np.zeros((H, W), np.int32)
+        frame[mine] = full[mine]                                   # rank 0 renders in place
+        for r in range(1, world):
+            rows = multigpu.native_frame_rows(H, world, r, block)
+            if len(rows) == 0:
+                continue
+            buf = torch.zeros((len(rows), W), dtype=torch.int32)
+            dist.recv(buf, src=r)
+            for k in range(len(rows)):                             # what scatter_rows does, row by row
+                frame[multigpu.gather_lib().mrt_gather_frame_row(H, world, block, r, k)] = buf[k].numpy()
+        np.save(out_path, frame)
+    elif len(mine):
+        dist.send(torch.from_numpy(np.ascontiguousarray(full[mine])), dst=0)      # packed share
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,block", [(2, 1), (2, 3)])
+def test_native_row_map_places_packed_shares(tmp_path, world, block):
+    """Two gloo ranks: rank 1 sends its packed share, rank 0 places the rows with the native library's row map."""
+    W, H = 64, 88
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_native_map_worker, args=(world, port, W, H, block, out), nprocs=world, join=True)
+    want = (np.arange(H, dtype=np.int32)[:, None] * 100000 + np.arange(W, dtype=np.int32)[None, :])
+    assert np.array_equal(np.load(out), want)
