@@ -69,7 +69,8 @@ struct FrameDev {
     // counters[0..15]: [5] watchdog code.  counters[kQueueBase + 16*q]: next index of tile queue q
     // (resident kernel), one cache line per queue.
     // Ray statistics live in kStatSlots groups of 16 words (128 bytes, one cache line each) after
-    // the queues: group s, word 0 primary rays, 1 shadow rays, 2 secondary rays, 3 primary hits.  A tile
+    // the queues: group s, word 0 = tiles (low 32 bits; 64 primary rays each) and primary hits (high 32 bits),
+    // word 1 = shadow rays minus (primary hits x lights), two's complement, word 2 = secondary rays.  A tile
     // adds into group (tile % kStatSlots) so that the atomics of concurrent waves spread over
     // many lines instead of queueing on one address; the host sums the groups.
     unsigned long long* counters;

@@ -804,10 +804,14 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
         const uint32_t sh = wave_sum(n_shadow), se = wave_sum(n_secondary);
         if (lane == 0) {
             unsigned long long* slot = F.counters + kStatBase + 16 * (tile % kStatSlots);
-            atomicAdd(&slot[0], 64ull);
-            if (sh) atomicAdd(&slot[1], (unsigned long long)sh);
+            // Counter updates are executed at the memory side (the XCDs' L2s do not share lines), so a tile
+            // sends as few as it can: one word carries the tile count (low half) and the primary hits (high
+            // half); shadow rays are sent as the difference from "one per primary hit and light", which is zero
+            // for a tile of the packet path on opaque-or-lit surfaces, and secondary rays only when there are any.
+            atomicAdd(&slot[0], 1ull | ((unsigned long long)hits << 32));
+            const long long extra_shadow = (long long)sh - (long long)hits * S.n_lights;
+            if (extra_shadow) atomicAdd(&slot[1], (unsigned long long)extra_shadow);
             if (se) atomicAdd(&slot[2], (unsigned long long)se);
-            if (hits) atomicAdd(&slot[3], (unsigned long long)hits);
         }
     }
 }

@@ -132,6 +132,7 @@ struct mrt_ctx {
     hipStream_t last_stream = nullptr;
     hipEvent_t last_done = nullptr;   // recorded after every frame launch: the context's counters and queues are shared,
     bool launched = false;            // so a launch on another stream first waits for the previous one
+    int last_n_lights = 0;                         // lights of the last launch (the shadow-ray counter is relative to it)
     unsigned long long* last_counters = nullptr;   // counter block the last launch used (the context's own or the GPU's scratch)
     unsigned char* scratch_dev = nullptr;          // this GPU's copy of the scratch array (mrt_render_device_noalloc)
     // ray arrays of the operator-level entry points, kept between calls (grown on demand)
@@ -295,6 +296,7 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
     c->last_stream = stream;
     c->launched = true;
     c->last_counters = F.counters;
+    c->last_n_lights = c->scene.n_lights;
     return MRT_OK;
 }
 
@@ -671,9 +673,17 @@ int mrt_get_ray_counts(mrt_ctx* c, uint64_t out[4]) {
     std::vector<unsigned long long> tmp(kCounterSlots);
     MRT_HIP(c, hipMemcpy(tmp.data(), c->last_counters ? c->last_counters : c->d_counters.p, kCounterSlots * sizeof(unsigned long long),
                          hipMemcpyDeviceToHost));
-    for (int i = 0; i < 4; ++i) out[i] = 0;
-    for (int s = 0; s < kStatSlots; ++s)
-        for (int i = 0; i < 4; ++i) out[i] += tmp[kStatBase + 16 * s + i];
+    unsigned long long tiles = 0, hits = 0, extra_shadow = 0, secondary = 0;
+    for (int s = 0; s < kStatSlots; ++s) {
+        const unsigned long long* g = &tmp[kStatBase + 16 * s];
+        tiles += g[0] & 0xffffffffull; hits += g[0] >> 32;
+        extra_shadow += g[1];                // differences, two's complement: the sum wraps to the right total
+        secondary += g[2];
+    }
+    out[0] = 64 * tiles;
+    out[1] = hits * (unsigned long long)c->last_n_lights + extra_shadow;
+    out[2] = secondary;
+    out[3] = hits;
     const unsigned long long wd = tmp[5];
     if (wd != 0) return fail(c, MRT_E_LIMIT, "a traversal loop exhausted its iteration budget (code " + std::to_string(wd) + ")");
     return MRT_OK;
