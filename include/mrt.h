@@ -96,6 +96,14 @@ int mrt_scene_upload(mrt_ctx* ctx, const mrt_mesh* meshes, int n_meshes,
 int mrt_scene_upload_lbvh(mrt_ctx* ctx, const mrt_mesh* meshes, int n_meshes,
                           const mrt_texture* textures, int n_textures);
 
+/* Moving geometry without a new tree.  The reference can only build again (Raytracer::BuildBVH, raytracer.cpp:670-673,
+ * the whole of BVH::BVH); this call keeps the tree the context holds -- the reference's or the GPU-built one -- takes the
+ * meshes' new vertex positions, normals and uvs (same meshes in the same order with the same triangle counts and vertex
+ * indices' meaning; MRT_E_ARG otherwise, and the old geometry stays in place), recomputes every node's box bottom-up and
+ * uploads.  Textures and lights stay.  Nearest hits are those of the moved geometry; as with any tree other than the
+ * one the reference would build for it, the triangle named on an exact distance tie may be the other one. */
+int mrt_scene_refit(mrt_ctx* ctx, const mrt_mesh* meshes, int n_meshes);
+
 /* Raytracer::m_Lights (raytracer.h:244; game.cpp:69-70 moves light 0): n records of
  * {pos.xyz, colour.xyzw} = 7 floats, colour in the reference's x=A,y=R,z=G,w=B order. */
 int mrt_set_lights(mrt_ctx* ctx, const float* pos_rgba7, int n);

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MRT_LIB") or os.path.join(_HERE, "libmrt.so")     # M
 MODE_PACKET = 0
 MODE_RECURSIVE = 1
 
-SYMBOLS = ("mrt_create", "mrt_destroy", "mrt_last_error", "mrt_version", "mrt_scene_upload", "mrt_scene_upload_lbvh",
+SYMBOLS = ("mrt_create", "mrt_destroy", "mrt_last_error", "mrt_version", "mrt_scene_upload", "mrt_scene_upload_lbvh", "mrt_scene_refit",
            "mrt_set_lights",
            "mrt_bvh_build_host", "mrt_render", "mrt_host_alloc", "mrt_host_free", "mrt_render_submit", "mrt_render_wait", "mrt_render_device", "mrt_render_device_noalloc", "mrt_render_device_part", "mrt_part_rows",
            "mrt_raster_render", "mrt_raster_render_device", "mrt_trace_packets",
@@ -73,6 +73,7 @@ def lib():
         L.mrt_last_error.restype = C.c_char_p
         L.mrt_scene_upload.argtypes = [vp, C.POINTER(_Mesh), i32, C.POINTER(_Texture), i32]
         L.mrt_scene_upload_lbvh.argtypes = [vp, C.POINTER(_Mesh), i32, C.POINTER(_Texture), i32]
+        L.mrt_scene_refit.argtypes = [vp, C.POINTER(_Mesh), i32]
         L.mrt_set_lights.argtypes = [vp, vp, i32]
         L.mrt_bvh_build_host.argtypes = [C.POINTER(_Mesh), i32, vp, vp, vp, vp]
         L.mrt_render.argtypes = [vp, vp, C.c_uint32, vp, i32, vp]
@@ -217,6 +218,12 @@ class Raytracer:
         fn = self.L.mrt_scene_upload_lbvh if lbvh else self.L.mrt_scene_upload
         self._check(fn(self.h, meshes, len(scene["meshes"]), textures, len(scene["textures"])),
                     "mrt_scene_upload_lbvh" if lbvh else "mrt_scene_upload")
+        del keep
+
+    def refit(self, scene):
+        """mrt_scene_refit: the same meshes with moved vertices; the tree is kept, its boxes are recomputed."""
+        meshes, _, keep = _pack_scene(scene)
+        self._check(self.L.mrt_scene_refit(self.h, meshes, len(scene["meshes"])), "mrt_scene_refit")
         del keep
 
     def set_lights(self, lights):

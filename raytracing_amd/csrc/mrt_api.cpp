@@ -385,25 +385,73 @@ int mrt_set_lights(mrt_ctx* c, const float* pos_rgba7, int n) {
     return MRT_OK;
 }
 
-static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures, bool lbvh);
+enum class TreeSource { Reference, Lbvh, Refit };
+static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures, TreeSource source);
 
 int mrt_scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures) {
-    return scene_upload(c, meshes, n_meshes, textures, n_textures, false);
+    return scene_upload(c, meshes, n_meshes, textures, n_textures, TreeSource::Reference);
 }
 
 int mrt_scene_upload_lbvh(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures) {
-    return scene_upload(c, meshes, n_meshes, textures, n_textures, true);
+    return scene_upload(c, meshes, n_meshes, textures, n_textures, TreeSource::Lbvh);
 }
 
-static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures, bool lbvh) {
+int mrt_scene_refit(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes) {
+    return scene_upload(c, meshes, n_meshes, nullptr, 0, TreeSource::Refit);
+}
+
+// New bounds for the tree the context holds, bottom-up, after its triangles have moved: a leaf's box spans its
+// triangles' vertices, an inner node's box its two children's.  Which triangles a leaf holds and how the nodes
+// hang together stays as it is.
+static void refit_bounds(HostBVH& B) {
+    if (B.n_tris == 0) return;
+    std::vector<uint32_t> order;             // nodes in pre-order: walked backwards, children come before their parent
+    order.reserve((size_t)B.pool_ptr + 1);
+    std::vector<uint32_t> todo{0u};
+    while (!todo.empty()) {
+        const uint32_t n = todo.back();
+        todo.pop_back();
+        order.push_back(n);
+        if (B.count[n] == 0) { todo.push_back(B.first[n]); todo.push_back(B.first[n] + 1); }
+    }
+    // leaves are independent of each other
+    parallel_for(order.size(), [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            const uint32_t n = order[i];
+            if (B.count[n] == 0) continue;
+            f3 lo = {1e30f, 1e30f, 1e30f}, hi = {-1e30f, -1e30f, -1e30f};       // raytracer.h:258-262 starts its boxes there
+            for (uint32_t k = B.first[n]; k < B.first[n] + B.count[n]; ++k) {
+                const HostTri& t = B.tris[B.idx[k]];
+                for (const f3& p : {t.p0, t.p1, t.p2}) {
+                    lo = {gmin(lo.x, p.x), gmin(lo.y, p.y), gmin(lo.z, p.z)};
+                    hi = {gmax(hi.x, p.x), gmax(hi.y, p.y), gmax(hi.z, p.z)};
+                }
+            }
+            B.nmin[n] = lo; B.nmax[n] = hi;
+        }
+    });
+    for (size_t i = order.size(); i-- > 0;) {
+        const uint32_t n = order[i];
+        if (B.count[n] != 0) continue;
+        const uint32_t l = B.first[n], r = l + 1;
+        B.nmin[n] = {gmin(B.nmin[l].x, B.nmin[r].x), gmin(B.nmin[l].y, B.nmin[r].y), gmin(B.nmin[l].z, B.nmin[r].z)};
+        B.nmax[n] = {gmax(B.nmax[l].x, B.nmax[r].x), gmax(B.nmax[l].y, B.nmax[r].y), gmax(B.nmax[l].z, B.nmax[r].z)};
+    }
+}
+
+static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures, TreeSource source) {
     if (!c) return MRT_E_ARG;
-    if (n_textures < 0 || (n_textures > 0 && !textures)) return fail(c, MRT_E_ARG, "bad texture array");
-    for (int i = 0; i < n_textures; ++i)
+    const bool lbvh = source == TreeSource::Lbvh, refit = source == TreeSource::Refit;
+    if (refit) {
+        if (!c->has_scene) return fail(c, MRT_E_STATE, "mrt_scene_refit needs a scene: call mrt_scene_upload first");
+        n_textures = c->scene.n_textures;          // the textures stay as they are
+    }
+    if (!refit && (n_textures < 0 || (n_textures > 0 && !textures))) return fail(c, MRT_E_ARG, "bad texture array");
+    for (int i = 0; i < n_textures && !refit; ++i)
         if (!textures[i].indices || !textures[i].palettes || textures[i].width <= 0 || textures[i].height <= 0)
             return fail(c, MRT_E_ARG, "bad texture");
     MRT_HIP(c, hipSetDevice(c->device));
     std::string err;
-    c->has_scene = false;
     const bool timing = env_int("MRT_TIMING", 0) != 0;             // stage times of the upload on stderr
     auto t_prev = std::chrono::steady_clock::now();
     auto stage = [&](const char* what) {
@@ -412,14 +460,29 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
         fprintf(stderr, "mrt_scene_upload: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
     };
-    if (!flatten_meshes(meshes, n_meshes, n_textures, true, c->bvh.tris, err)) return fail(c, MRT_E_ARG, err);
-    stage("flatten");
-    if (lbvh && !c->bvh.tris.empty()) {
+    if (refit) {
+        // the context stays usable with its old geometry if the new one is refused
+        std::vector<HostTri> moved;
+        if (!flatten_meshes(meshes, n_meshes, n_textures, true, moved, err)) return fail(c, MRT_E_ARG, err);
+        if (moved.size() != c->bvh.tris.size())
+            return fail(c, MRT_E_ARG, "mrt_scene_refit: " + std::to_string(moved.size()) + " triangles, the uploaded scene has " +
+                                      std::to_string(c->bvh.tris.size()) + " (a refit keeps the tree: same meshes, same triangle counts)");
+        c->has_scene = false;
+        c->bvh.tris.swap(moved);
+        stage("flatten");
+        refit_bounds(c->bvh);
+    } else {
+        c->has_scene = false;
+        if (!flatten_meshes(meshes, n_meshes, n_textures, true, c->bvh.tris, err)) return fail(c, MRT_E_ARG, err);
+        stage("flatten");
+    }
+    if (refit) {
+    } else if (lbvh && !c->bvh.tris.empty()) {
         if (!build_lbvh_device(c->bvh, c->stream, err)) return fail(c, MRT_E_HIP, err);
     } else {
         build_bvh(c->bvh);
     }
-    stage(lbvh ? "tree (GPU)" : "tree (host)");
+    stage(refit ? "bounds (refit)" : lbvh ? "tree (GPU)" : "tree (host)");
     const HostBVH& B = c->bvh;
     if (B.max_depth + 2 > kStackDepth) return fail(c, MRT_E_LIMIT, "BVH deeper than the traversal stack (62 levels)");
     if (B.pool_ptr >= (1u << 26)) return fail(c, MRT_E_LIMIT, "too many BVH nodes for the packet work list encoding");
@@ -461,10 +524,10 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
             attr[4 * id + 3] = make_float4(bits2f((uint32_t)t.tex), 0, 0, 0);
         }
     });
-    std::vector<int4> tex(n_textures);
+    std::vector<int4> tex(refit ? 0 : n_textures);
     std::vector<uint8_t> texels;
-    std::vector<uint32_t> pal((size_t)n_textures * 32 * 256);
-    for (int i = 0; i < n_textures; ++i) {
+    std::vector<uint32_t> pal(refit ? 0 : (size_t)n_textures * 32 * 256);
+    for (int i = 0; i < n_textures && !refit; ++i) {
         const size_t n = (size_t)textures[i].width * textures[i].height;
         tex[i] = make_int4((int)texels.size(), textures[i].width, textures[i].height, 0);
         texels.insert(texels.end(), textures[i].indices, textures[i].indices + n);
@@ -477,9 +540,11 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     MRT_HIP(c, c->d_triB.upload(triB, c->stream));
     MRT_HIP(c, c->d_triC.upload(triC, c->stream));
     MRT_HIP(c, c->d_attr.upload(attr, c->stream));
-    MRT_HIP(c, c->d_tex.upload(tex, c->stream));
-    MRT_HIP(c, c->d_texels.upload(texels, c->stream));
-    MRT_HIP(c, c->d_pal.upload(pal, c->stream));
+    if (!refit) {
+        MRT_HIP(c, c->d_tex.upload(tex, c->stream));
+        MRT_HIP(c, c->d_texels.upload(texels, c->stream));
+        MRT_HIP(c, c->d_pal.upload(pal, c->stream));
+    }
     MRT_HIP(c, c->d_lights.upload(c->lights, c->stream));
     stage("upload ray-path arrays");
     if (int rc = raster_upload(c->raster, meshes, n_meshes, c->stream, err)) return fail(c, rc, err);
