@@ -4,13 +4,16 @@
 //
 //   mrt_game [--scene assets/maze.obj | scene.mrts] [--size W H] [--frames N]
 //            [--mode packet|recursive|raster] [--pos x y z --lookat x y z]
-//            [--out frame.ppm] [--dump-scene out.mrts] [--device N]
+//            [--out frame.ppm|frame.png] [--out-sequence prefix] [--overlay] [--dump-scene out.mrts] [--device N]
 //            [--script "W*30 RIGHT*10 O*5 SPACE*1" --dt 0.016] [--no-render] [--pipeline]
 //            [--ranks N --rank R --nccl-id FILE [--block B] [--spp-grid G]]  |  [--rehearse-ranks N]
 //
 // --script replays Game::HandleInput (game.cpp:41-75) without a keyboard: each token holds one key for N
 // frames of length dt (W S A D R F move, LEFT RIGHT UP DOWN turn, O P move the light, SPACE switches
 // between ray tracer and rasterizer).  --no-render runs the script only and prints the final state.
+// --overlay draws the reference's frame-time / FPS lines into every frame (game.cpp:95-112), updated once per second of
+// frame time like there; --out-sequence writes every frame as prefix_0000.png, prefix_0001.png, ... (the stand-in for the
+// window the reference presents its Surface in, template.cpp:111-127).
 // --pipeline keeps the next frame in flight while the finished one is presented (two Surfaces,
 // mrt_render_submit / mrt_render_wait); ray-traced frames only.
 // --ranks N --rank R: one process per GPU (GPU R unless --device says otherwise).  The scene is replicated,
@@ -141,7 +144,8 @@ int main(int argc, char** argv) {
     MultiOpts multi;
     std::string scene_file = "assets/maze.obj", mode = "packet", out, dump, script;
     float dt = 0.016f;
-    bool no_render = false, pipeline = false;
+    bool no_render = false, pipeline = false, overlay = false;
+    std::string sequence;
     int W = 800, H = 600, frames = 10, device = -1;       // game.h:3-4
     bool have_pose = false;
     vec3 pos{0, 0, 0}, target{0, 0, -1};
@@ -158,6 +162,8 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--dt")) { need(1); dt = (float)atof(argv[++i]); }
         else if (!strcmp(argv[i], "--no-render")) no_render = true;
         else if (!strcmp(argv[i], "--pipeline")) pipeline = true;
+        else if (!strcmp(argv[i], "--overlay")) overlay = true;
+        else if (!strcmp(argv[i], "--out-sequence")) { need(1); sequence = argv[++i]; }
         else if (!strcmp(argv[i], "--ranks")) { need(1); multi.ranks = atoi(argv[++i]); }
         else if (!strcmp(argv[i], "--rank")) { need(1); multi.rank = atoi(argv[++i]); }
         else if (!strcmp(argv[i], "--nccl-id")) { need(1); multi.id_file = argv[++i]; }
@@ -221,6 +227,26 @@ int main(int argc, char** argv) {
 
         double total_ms = 0, best_ms = 1e30;
         uint64_t rays[4] = {0, 0, 0, 0};
+        // Game::Tick's counters (game.cpp:95-105): frames and their time are added up, and once a second of frame time has
+        // passed the displayed values are refreshed
+        int tick_frames = 0, frames_per_second = 0;
+        float tick_time = 0.0f, frame_duration = 0.0f;
+        auto present = [&](Surface& shown, int frame_no, float frame_dt) {
+            tick_frames++;
+            tick_time += frame_dt;
+            if (tick_time >= 1.0f) {
+                frames_per_second = tick_frames;
+                frame_duration = tick_time / (float)tick_frames;
+                tick_frames = 0;
+                tick_time = 0.0f;
+            }
+            if (overlay) shown.PrintFrameStats(frame_duration, frames_per_second);
+            if (!sequence.empty()) {
+                char name[32];
+                snprintf(name, sizeof name, "_%04d.png", frame_no);
+                if (!shown.SavePNG(sequence + name)) throw std::runtime_error("cannot write " + sequence + name);
+            }
+        };
         for (int f = 0; f < frames; ++f) {                      // Game::Tick
             if (!keys.empty()) {                                // Game::HandleInput, game.cpp:41-75
                 const std::string& k = keys[f];
@@ -251,11 +277,13 @@ int main(int argc, char** argv) {
                     raytracer.Wait(prev_ticket);
                     Surface* shown = f % 2 ? &screen : &screen2;
                     for (int i = 0; i < W * H; i += 4099) shown_sum += shown->GetBuffer()[i];
+                    present(*shown, f - 1, keys.empty() ? (float)(total_ms / (f > 1 ? f - 1 : 1) * 1e-3) : dt);
                 }
                 prev_ticket = ticket;
                 if (f == frames - 1) {
                     raytracer.Wait(ticket);
                     if (target != &screen) memcpy(screen.GetBuffer(), target->GetBuffer(), (size_t)W * H * sizeof(uint32_t));
+                    present(screen, f, keys.empty() ? (float)(total_ms / (f > 1 ? f - 1 : 1) * 1e-3) : dt);
                 }
                 const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts).count();
                 if (f > 0 || frames == 1) { total_ms += ms; best_ms = ms < best_ms ? ms : best_ms; }
@@ -269,6 +297,7 @@ int main(int argc, char** argv) {
             else { fprintf(stderr, "unknown mode %s\n", mode.c_str()); return 2; }
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (f > 0 || frames == 1) { total_ms += ms; best_ms = ms < best_ms ? ms : best_ms; }
+            present(screen, f, keys.empty() ? (float)(ms * 1e-3) : dt);      // a replayed script advances by its own dt, as Tick(dt) does
         }
         if (!keys.empty()) {
             printf("camera:");
@@ -286,7 +315,8 @@ int main(int argc, char** argv) {
         if (n_rays > 0) printf(", %.0f rays/frame, %.1f Mrays/s (host framebuffer copy included)", n_rays, n_rays / per_frame_ms / 1e3);
         if (pipeline) printf(" [pipelined, checksum %llx]", shown_sum);
         printf("\n");
-        if (!out.empty() && screen.SavePPM(out)) printf("wrote %s\n", out.c_str());
+        const bool png = out.size() > 4 && out.substr(out.size() - 4) == ".png";
+        if (!out.empty() && (png ? screen.SavePNG(out) : screen.SavePPM(out))) printf("wrote %s\n", out.c_str());
     } catch (const std::exception& e) {
         fprintf(stderr, "mrt_game: %s\n", e.what());
         return 1;

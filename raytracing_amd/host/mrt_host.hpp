@@ -66,6 +66,138 @@ struct Surface {                       // surface.h:57-100 (pixel storage only)
         fclose(f);
         return true;
     }
+    // Surface::Print (surface.cpp:175-199): 5 x 5 pixel glyphs, 6 pixels apart, upper case drawn as lower case, only
+    // the set dots of a glyph touch the frame.  The glyph shapes here are this file's own (digits, letters and the
+    // punctuation the overlay and a driver's messages need; anything else prints as a blank), and, unlike the
+    // reference, dots that would fall outside the frame are dropped instead of written.
+    void Print(const char* text, int x1, int y1, uint32_t color) {
+        for (int i = 0; text[i]; ++i) {
+            const uint32_t g = Glyph(text[i]);
+            for (int v = 0; v < 5; ++v)
+                for (int h = 0; h < 5; ++h) {
+                    const int x = x1 + 6 * i + h, y = y1 + v;
+                    if (((g >> (24 - (5 * v + h))) & 1u) && x >= 0 && y >= 0 && x < width && y < height) buffer[(size_t)y * pitch + x] = color;
+                }
+        }
+    }
+    // The reference's per-frame overlay (game.cpp:95-112): two lines at (2,2) and (2,12) in 0xff00ff.
+    void PrintFrameStats(float frame_duration_s, int frames_per_second) {
+        char line[64];
+        snprintf(line, sizeof line, "Frametime : %f", frame_duration_s);
+        Print(line, 2, 2, 0xff00ff);
+        snprintf(line, sizeof line, "FPS       : %i", frames_per_second);
+        Print(line, 2, 12, 0xff00ff);
+    }
+    // The frame as a PNG file (8-bit RGB, alpha dropped like the PPM): what stands in for the window the reference
+    // presents its Surface in (template.cpp:111-127).  No compression library: the image data is a zlib stream of
+    // stored blocks.
+    bool SavePNG(const std::string& path) const {
+        std::vector<unsigned char> raw((size_t)height * (1 + 3 * (size_t)width));
+        for (int y = 0; y < height; ++y) {
+            unsigned char* row = raw.data() + (size_t)y * (1 + 3 * (size_t)width);
+            row[0] = 0;                                        // filter type: none
+            for (int x = 0; x < width; ++x) {
+                const uint32_t p = buffer[(size_t)y * pitch + x];
+                row[1 + 3 * x] = (unsigned char)(p >> 16); row[2 + 3 * x] = (unsigned char)(p >> 8); row[3 + 3 * x] = (unsigned char)p;
+            }
+        }
+        std::vector<unsigned char> z = {0x78, 0x01};           // zlib header: deflate, 32 KiB window, no preset dictionary
+        uint32_t a = 1, b = 0;                                 // Adler-32 of the uncompressed data
+        for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
+            const size_t n = std::min<size_t>(65535, raw.size() - off);
+            const bool last = off + n >= raw.size();
+            z.push_back(last ? 1 : 0);                         // stored block
+            z.push_back((unsigned char)(n & 255)); z.push_back((unsigned char)(n >> 8));
+            z.push_back((unsigned char)(~n & 255)); z.push_back((unsigned char)((~n >> 8) & 255));
+            z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+            for (size_t i = off; i < off + n; ++i) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+            if (last) break;
+        }
+        const uint32_t adler = (b << 16) | a;
+        for (int s = 24; s >= 0; s -= 8) z.push_back((unsigned char)(adler >> s));
+        FILE* f = fopen(path.c_str(), "wb");
+        if (!f) return false;
+        static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+        bool ok = fwrite(sig, 1, 8, f) == 8;
+        unsigned char ihdr[13];
+        PutBE(ihdr, (uint32_t)width); PutBE(ihdr + 4, (uint32_t)height);
+        ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;   // 8 bits, RGB, deflate, adaptive filters, no interlace
+        ok = ok && Chunk(f, "IHDR", ihdr, 13) && Chunk(f, "IDAT", z.data(), z.size()) && Chunk(f, "IEND", nullptr, 0);
+        return fclose(f) == 0 && ok;
+    }
+
+private:
+    static void PutBE(unsigned char* p, uint32_t v) { p[0] = (unsigned char)(v >> 24); p[1] = (unsigned char)(v >> 16); p[2] = (unsigned char)(v >> 8); p[3] = (unsigned char)v; }
+    static uint32_t Crc(uint32_t crc, const unsigned char* p, size_t n) {      // CRC-32 (reflected 0xedb88320), bit by bit
+        for (size_t i = 0; i < n; ++i) {
+            crc ^= p[i];
+            for (int k = 0; k < 8; ++k) crc = (crc >> 1) ^ (0xedb88320u & (0u - (crc & 1u)));
+        }
+        return crc;
+    }
+    static bool Chunk(FILE* f, const char type[4], const unsigned char* data, size_t n) {
+        unsigned char len[4], tail[4];
+        PutBE(len, (uint32_t)n);
+        uint32_t crc = Crc(0xffffffffu, reinterpret_cast<const unsigned char*>(type), 4);
+        if (n) crc = Crc(crc, data, n);
+        PutBE(tail, ~crc);
+        return fwrite(len, 1, 4, f) == 4 && fwrite(type, 1, 4, f) == 4 && (n == 0 || fwrite(data, 1, n, f) == n) && fwrite(tail, 1, 4, f) == 4;
+    }
+    // 25 bits per glyph, row by row from the top, the leftmost dot of a row in the higher bit
+    static constexpr uint32_t Rows(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t r4) { return (r0 << 20) | (r1 << 15) | (r2 << 10) | (r3 << 5) | r4; }
+    static uint32_t Glyph(char ch) {
+        if (ch >= 'A' && ch <= 'Z') ch = (char)(ch - 'A' + 'a');
+        switch (ch) {
+            case '0': return Rows(0b01110, 0b10011, 0b10101, 0b11001, 0b01110);
+            case '1': return Rows(0b00100, 0b01100, 0b00100, 0b00100, 0b01110);
+            case '2': return Rows(0b11110, 0b00001, 0b01110, 0b10000, 0b11111);
+            case '3': return Rows(0b11110, 0b00001, 0b01110, 0b00001, 0b11110);
+            case '4': return Rows(0b10010, 0b10010, 0b11111, 0b00010, 0b00010);
+            case '5': return Rows(0b11111, 0b10000, 0b11110, 0b00001, 0b11110);
+            case '6': return Rows(0b01110, 0b10000, 0b11110, 0b10001, 0b01110);
+            case '7': return Rows(0b11111, 0b00001, 0b00010, 0b00100, 0b00100);
+            case '8': return Rows(0b01110, 0b10001, 0b01110, 0b10001, 0b01110);
+            case '9': return Rows(0b01110, 0b10001, 0b01111, 0b00001, 0b01110);
+            case 'a': return Rows(0b01110, 0b10001, 0b11111, 0b10001, 0b10001);
+            case 'b': return Rows(0b11110, 0b10001, 0b11110, 0b10001, 0b11110);
+            case 'c': return Rows(0b01111, 0b10000, 0b10000, 0b10000, 0b01111);
+            case 'd': return Rows(0b11110, 0b10001, 0b10001, 0b10001, 0b11110);
+            case 'e': return Rows(0b11111, 0b10000, 0b11110, 0b10000, 0b11111);
+            case 'f': return Rows(0b11111, 0b10000, 0b11100, 0b10000, 0b10000);
+            case 'g': return Rows(0b01111, 0b10000, 0b10011, 0b10001, 0b01110);
+            case 'h': return Rows(0b10001, 0b10001, 0b11111, 0b10001, 0b10001);
+            case 'i': return Rows(0b01110, 0b00100, 0b00100, 0b00100, 0b01110);
+            case 'j': return Rows(0b00111, 0b00010, 0b00010, 0b10010, 0b01100);
+            case 'k': return Rows(0b10010, 0b10100, 0b11000, 0b10100, 0b10010);
+            case 'l': return Rows(0b10000, 0b10000, 0b10000, 0b10000, 0b11111);
+            case 'm': return Rows(0b10001, 0b11011, 0b10101, 0b10001, 0b10001);
+            case 'n': return Rows(0b10001, 0b11001, 0b10101, 0b10011, 0b10001);
+            case 'o': return Rows(0b01110, 0b10001, 0b10001, 0b10001, 0b01110);
+            case 'p': return Rows(0b11110, 0b10001, 0b11110, 0b10000, 0b10000);
+            case 'q': return Rows(0b01110, 0b10001, 0b10001, 0b10011, 0b01111);
+            case 'r': return Rows(0b11110, 0b10001, 0b11110, 0b10100, 0b10010);
+            case 's': return Rows(0b01111, 0b10000, 0b01110, 0b00001, 0b11110);
+            case 't': return Rows(0b11111, 0b00100, 0b00100, 0b00100, 0b00100);
+            case 'u': return Rows(0b10001, 0b10001, 0b10001, 0b10001, 0b01110);
+            case 'v': return Rows(0b10001, 0b10001, 0b01010, 0b01010, 0b00100);
+            case 'w': return Rows(0b10001, 0b10001, 0b10101, 0b11011, 0b10001);
+            case 'x': return Rows(0b10001, 0b01010, 0b00100, 0b01010, 0b10001);
+            case 'y': return Rows(0b10001, 0b01010, 0b00100, 0b00100, 0b00100);
+            case 'z': return Rows(0b11111, 0b00010, 0b00100, 0b01000, 0b11111);
+            case ':': return Rows(0b00000, 0b00100, 0b00000, 0b00100, 0b00000);
+            case '.': return Rows(0b00000, 0b00000, 0b00000, 0b00000, 0b00100);
+            case ',': return Rows(0b00000, 0b00000, 0b00000, 0b00100, 0b01000);
+            case '-': return Rows(0b00000, 0b00000, 0b01110, 0b00000, 0b00000);
+            case '+': return Rows(0b00000, 0b00100, 0b01110, 0b00100, 0b00000);
+            case '/': return Rows(0b00001, 0b00010, 0b00100, 0b01000, 0b10000);
+            case '%': return Rows(0b11001, 0b11010, 0b00100, 0b01011, 0b10011);
+            case '(': return Rows(0b00010, 0b00100, 0b00100, 0b00100, 0b00010);
+            case ')': return Rows(0b01000, 0b00100, 0b00100, 0b00100, 0b01000);
+            default: return 0;
+        }
+    }
+
+public:
 };
 
 struct Camera {                        // scenedata.h:125-137; transform is column-major like glm::mat4

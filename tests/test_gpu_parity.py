@@ -603,6 +603,36 @@ def test_cpp_host_driver_split_render_with_native_gather(args):
     assert r.returncode == 0 and "is identical to the undivided frame" in r.stdout, r.stdout[-400:] + r.stderr[-400:]
 
 
+def test_cpp_host_driver_overlay_and_png_sequence(tmp_path, known):
+    """mrt_game --overlay --out-sequence: every frame lands as a PNG; outside the two overlay lines the pixels are the
+    reference frame's (800x600, default camera, packet path: the recorded hash), inside them some are the overlay's
+    magenta."""
+    import os
+    import struct
+    import subprocess
+    import zlib
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "raytracing_amd", "host", "mrt_game")
+    prefix = str(tmp_path / "seq")
+    subprocess.check_call([exe, "--scene", os.path.join(ROOT, "tests", "golden", "maze.mrts"), "--size", "800", "600", "--mode", "packet",
+                           "--frames", "3", "--overlay", "--out-sequence", prefix])
+    rt = Raytracer(800, 600, device=0)
+    rt.build_bvh(scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "maze.mrts")))
+    fb, _ = rt.render(oracle_lib.IDENTITY, mode=MODE_PACKET)
+    rt.close()
+    assert "%016x" % oracle_lib.fbhash(fb) == known["packet_frames"][1]["fbhash"]
+    for k in range(3):
+        data = open("%s_%04d.png" % (prefix, k), "rb").read()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n" and struct.unpack(">II", data[16:24]) == (800, 600)
+        n = struct.unpack(">I", data[33:37])[0]
+        raw = np.frombuffer(zlib.decompress(data[41:41 + n]), np.uint8).reshape(600, 1 + 3 * 800)[:, 1:].reshape(600, 800, 3).astype(np.uint32)
+        px = (raw[..., 0] << 16) | (raw[..., 1] << 8) | raw[..., 2]
+        outside = np.ones((600, 800), bool)
+        outside[2:17, 2:2 + 6 * 24] = False
+        assert np.array_equal(px[outside], (fb & 0xFFFFFF)[outside])
+        assert (px[2:17, 2:2 + 6 * 24] == 0xFF00FF).sum() > 100
+
+
 def test_random_pose_campaign():
     """scripts/parity_fuzz.py: 80 random cameras (some on integer coordinates, some looking straight down), random
     light positions, four frame sizes, every fifth pose with a 2x2 sample grid, both shaders."""

@@ -245,3 +245,49 @@ def test_driver_input_script_follows_handle_input():
     assert got_cam == [int(x) for x in M.view(np.uint32)]
     assert got_light == int(np.array([light], np.float32).view(np.uint32)[0])
     assert ("renderer: rasterizer" in r.stdout) == (not ray)
+
+
+def test_overlay_text_and_png_sink(tmp_path):
+    """The host driver's stand-ins for the reference's presentation step: Surface::Print-style overlay text (5 x 5 glyphs,
+    6 pixels apart, the two lines of game.cpp:108-112 at (2,2) and (2,12) in 0xff00ff) and a PNG writer.  The PNG is
+    parsed here with zlib: signature, chunk CRCs, image data."""
+    import struct
+    import subprocess
+    import zlib
+    exe, png = str(tmp_path / "host_image"), str(tmp_path / "frame.png")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "native", "host_image.cpp"),
+                           "-L" + os.path.join(ROOT, "raytracing_amd"), "-lmrt", "-Wl,-rpath," + os.path.join(ROOT, "raytracing_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    W, H = 400, 70                     # 84,070 bytes of image data: more than one 65,535-byte stored block
+    subprocess.check_call([exe, png, str(W), str(H)])
+    data = open(png, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(data):
+        n, kind = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(kind + body) & 0xFFFFFFFF
+        chunks.append((kind, body))
+        pos += 12 + n
+    assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (W, H, 8, 2, 0, 0, 0)
+    raw = zlib.decompress(chunks[1][1])
+    assert len(raw) == H * (1 + 3 * W) > 65535                    # more than one stored block
+    rows = np.frombuffer(raw, np.uint8).reshape(H, 1 + 3 * W)
+    assert (rows[:, 0] == 0).all()
+    rgb = rows[:, 1:].reshape(H, W, 3).astype(np.uint32)
+    px = (rgb[..., 0] << 16) | (rgb[..., 1] << 8) | rgb[..., 2]
+    text = px == 0xFF00FF
+    ys, xs = np.nonzero(text)
+    assert set(ys.tolist()) <= set(range(2, 7)) | set(range(12, 17)) and xs.min() == 2
+    # "Frametime : 0.001234" is 20 characters, "FPS       : 810" 15: the last dots sit in their last cells
+    assert xs[ys < 7].max() <= 2 + 6 * 19 + 4 and xs[ys >= 12].max() <= 2 + 6 * 14 + 4 and xs[ys >= 12].max() >= 2 + 6 * 14
+    f_glyph = text[2:7, 2:7]
+    assert f_glyph[:, 0].all() and f_glyph[0].all() and not f_glyph[4, 1:].any()        # an F: stem, top bar, empty foot
+    assert not text[2:7, 7].any() and not text[2:7, 2 + 6 * 9:2 + 6 * 10].any()         # gap column; the blank before ':'
+    white = px == 0xFFFFFF
+    assert np.array_equal(white[22:27, 2:7], white[22:27, 2 + 18:7 + 18])               # 'A' and 'a' draw the same glyph
+    assert not white[22:27, 2 + 6 * 9:].any()                                           # '?' is a blank
+    green = px == 0x00FF00
+    assert green.any() and green[:H - 3].sum() == 0                                     # clipped at the edges, nothing wrapped around
+    assert (px[~(text | white | green)] == 0x102030).all()
