@@ -40,6 +40,7 @@ extern "C" {
 /* render flags (mrt_render / mrt_render_device) */
 #define MRT_MODE_PACKET     0u        /* Raytracer::Render: 64-ray packets + direct light (raytracer.cpp:420-463, 524-574) */
 #define MRT_MODE_RECURSIVE  1u        /* per-pixel GetColorFromSphere: reflection/refraction (raytracer.cpp:465-490, 575-664) */
+#define MRT_MODE_BVH_DEPTH  2u        /* the BVH-depth view (raytracer.cpp:581-586, 1265-1326): whole frames, no sample grid */
 #define MRT_MODE_MASK       0xffu
 #define MRT_SPP_GRID(g)     (((uint32_t)(g) & 0xffu) << 8)   /* g in {1,2,4,8}: g*g samples per pixel */
 #define MRT_FLAG_FRAME_ORDER   (1u << 16)  /* hand tiles out in frame order, like the counter of threads.cpp:165, instead of
@@ -107,6 +108,24 @@ int mrt_scene_refit(mrt_ctx* ctx, const mrt_mesh* meshes, int n_meshes);
 /* Raytracer::m_Lights (raytracer.h:244; game.cpp:69-70 moves light 0): n records of
  * {pos.xyz, colour.xyzw} = 7 floats, colour in the reference's x=A,y=R,z=G,w=B order. */
 int mrt_set_lights(mrt_ctx* ctx, const float* pos_rgba7, int n);
+
+/* Raytracer::m_Objects (raytracer.h:243): the analytic primitives of raytracer.h:84-123 / raytracer.cpp:146-213, Sphere
+ * (pos = centre, param = radius) and Plane (pos = normal, param = m_Dist), with the reference's Intersect, IsOccluded
+ * and HitNormal.  The reference fills this list (two spheres, raytracer.cpp:404-412) but never traces it; this library
+ * does not create them by itself either.  When a list is set, every ray that has searched the BVH also intersects the
+ * objects in list order (the nearest hit wins, a triangle on an exact tie), an object is shaded with its normal, its
+ * diffuse colour (x=A,y=R,z=G,w=B like every colour here) and its own refl / refr / rindex, shadow rays are blocked by
+ * any object whose IsOccluded says so, and hit_ids reports object k as -2 - k.  n = 0 removes the list. */
+#define MRT_OBJECT_SPHERE 0
+#define MRT_OBJECT_PLANE  1
+typedef struct mrt_object {
+    int32_t kind;
+    float   pos[3];
+    float   param;
+    float   diffuse[4];
+    float   refl, refr, rindex;
+} mrt_object;
+int mrt_set_objects(mrt_ctx* ctx, const mrt_object* objects, int n);
 
 /* Host-only BVH build with the arrays handed back, for inspection and tests; needs no GPU
  * and no context.  BVH::BVH + BVHNode::Subdivide (raytracer.cpp:897-1203).

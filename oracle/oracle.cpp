@@ -353,6 +353,93 @@ static int bvh_traverse(const BVH& b, Ray& r, HitRec& res) {
     return 0;
 }
 
+// raytracer.cpp:1265-1326 BVHNode::TraverseDepth (TEST 0 branch) and :951-954 BVH::TraverseDepth: the nearest-hit
+// traversal of the BVH-depth view.  It differs from BVHNode::Traverse in three ways: no root gate, `depth` counts
+// every node entered, and a child box passes only with tFar > tNear (strictly).
+static int traverse_depth(const BVH& b, uint32_t ni, Ray& r, int& depth, HitRec& res) {
+    const Node& n = b.nodes[ni];
+    depth++;
+    if (n.count != 0) return leaf_scalar(b, n, r, res);
+    const uint32_t li = n.firstLeft, ri = li + 1;
+    auto passes = [&](const Node& c, float& tNear) {
+        vec3 tMin = (c.mn - r.O) / r.D, tMax = (c.mx - r.O) / r.D;
+        vec3 t1 = vmin(tMin, tMax), t2 = vmax(tMin, tMax);
+        tNear = gmax(gmax(t1.x, t1.y), t1.z);
+        float tFar = gmin(gmin(t2.x, t2.y), t2.z);
+        return (tFar > tNear) && (tNear < r.t) && (tFar > 0);
+    };
+    float tNear, tNear2;
+    const bool leftN = passes(b.nodes[li], tNear), rightN = passes(b.nodes[ri], tNear2);
+    if (leftN) {
+        if (rightN) {
+            if (tNear2 < tNear) {
+                int hit = traverse_depth(b, ri, r, depth, res);
+                hit += traverse_depth(b, li, r, depth, res);
+                return hit;
+            }
+            int hit = traverse_depth(b, li, r, depth, res);
+            hit += traverse_depth(b, ri, r, depth, res);
+            return hit;
+        }
+        return traverse_depth(b, li, r, depth, res);
+    } else if (rightN) {
+        return traverse_depth(b, ri, r, depth, res);
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Analytic primitives (raytracer.h:60-123, raytracer.cpp:146-213): Sphere and Plane, with the reference's
+// Intersect / IsOccluded / HitNormal.  The reference keeps a list of them (raytracer.h:243) but never traces it
+// ("ATM all objects are triangles", raytracer.cpp:594); how they join a frame is defined in trace_objects below.
+// ------------------------------------------------------------------------------------------
+struct Object {
+    int kind;            // 0 sphere, 1 plane
+    vec3 pos;            // centre | plane normal ("Plane normal is stored in pos")
+    float param;         // radius | m_Dist
+    vec4 diffuse;        // m_Diffuse
+    float refl, refr, rindex;
+};
+static inline bool object_intersect(const Object& o, Ray& a_Ray) {
+    if (o.kind == 0) {                              // raytracer.cpp:153-169
+        vec3 c = o.pos - a_Ray.O;
+        float t = dot(c, a_Ray.D);
+        if (t < 0.0f) return false;
+        vec3 q = c - t * a_Ray.D;
+        float p2 = dot(q, q);
+        float r2 = o.param * o.param;
+        if (p2 > r2) return false;
+        t -= sqrtf(r2 - p2);
+        if (t < a_Ray.t) { a_Ray.t = t; return true; }
+        return false;
+    }
+    float dnd = dot(o.pos, a_Ray.D);                // raytracer.cpp:189-202
+    if (dnd == 0.0f) return false;
+    float t = -(dot(o.pos, a_Ray.O) + o.param) / dnd;
+    if (t < 0.0f) return false;
+    if (t < a_Ray.t) { a_Ray.t = t; return true; }
+    return false;
+}
+static inline bool object_occludes(const Object& o, const Ray& a_Ray) {
+    if (o.kind == 0) {                              // raytracer.cpp:170-180
+        vec3 c = o.pos - a_Ray.O;
+        float t = dot(c, a_Ray.D);
+        if (t < 0.0f) return false;
+        vec3 q = c - t * a_Ray.D;
+        float p2 = dot(q, q);
+        float r2 = o.param * o.param;
+        return p2 < r2;
+    }
+    float dnd = dot(o.pos, a_Ray.D);                // raytracer.cpp:203-213
+    if (dnd == 0) return false;
+    float t = -(dot(o.pos, a_Ray.O) + o.param) / dnd;
+    return !(t < 0.0f);
+}
+static inline vec3 object_normal(const Object& o, const vec3& a_Pos) {
+    if (o.kind == 0) return (a_Pos - o.pos) / o.param;   // raytracer.cpp:149-152
+    return o.pos;                                        // raytracer.cpp:185-188
+}
+
 // ------------------------------------------------------------------------------------------
 // Packet traversal (raytracer.h:207-212, raytracer.cpp:1349-1464)
 // ------------------------------------------------------------------------------------------
@@ -473,10 +560,25 @@ static inline vec3 reflect(vec3 I, vec3 N) {
 struct Tracer {
     const BVH* bvh;
     std::vector<Light> lights;
+    std::vector<Object> objects;
 };
 
+// How the analytic primitives join a frame (this build's definition; the reference has none):
+//  - after the BVH has been searched, every object is intersected in list order with the ray's current t
+//    (Object::Intersect shortens t only for a nearer hit), so the nearest of triangles and objects wins and a
+//    triangle wins an exact tie; the hit is reported as id -2 - (object index);
+//  - an object's surface is its HitNormal, its m_Diffuse as the colour and its own m_Refl / m_Refr / m_RIndex;
+//  - a shadow ray is blocked if the BVH blocks it or any object's IsOccluded says so.
+static inline int trace_objects(const Tracer& T, Ray& r) {
+    int which = -1;
+    for (size_t k = 0; k < T.objects.size(); ++k)
+        if (object_intersect(T.objects[k], r)) which = (int)k;
+    return which;
+}
+struct SurfaceMaterial { float refl, refr, rindex; };
+
 // raytracer.cpp:551-570 / 604-623 direct light for one surface point
-static inline void direct_light(const Tracer& T, const Triangle& tri, vec3 hit, vec3 normal, vec4 colorP, vec4& finalColor) {
+static inline void direct_light(const Tracer& T, const SurfaceMaterial& tri, vec3 hit, vec3 normal, vec4 colorP, vec4& finalColor) {
     float lightStrength = 1.0f - (tri.refr + tri.refl);
     if (lightStrength > 0.0f) {
         finalColor = finalColor + (AMBIENT * colorP) * lightStrength;
@@ -485,7 +587,9 @@ static inline void direct_light(const Tracer& T, const Triangle& tri, vec3 hit, 
             Ray lightRay{hit, normalize(light.pos - hit), INFINITY};
             HitRec r{-1, 0, 0};
             if (g_ctr) g_ctr->shadow_rays++;
-            if (bvh_traverse(*T.bvh, lightRay, r) == 0) {   // raytracer.cpp:414-418 IsOccluded
+            bool occluded = bvh_traverse(*T.bvh, lightRay, r) != 0;   // raytracer.cpp:414-418 IsOccluded
+            for (size_t k = 0; k < T.objects.size() && !occluded; ++k) occluded = object_occludes(T.objects[k], lightRay);
+            if (!occluded) {
                 float d = dot(normal, lightRay.D);
                 if (d < 0.0f) d = 0.0f;
                 finalColor = finalColor + ((d * light.color) * colorP) * lightStrength;
@@ -499,13 +603,29 @@ static void trace_packet(const Tracer& T, RayPacket& p, vec4* color, HitPacket& 
     for (int i = 0; i < PACKETSIZE; ++i) res.tri[i] = -1;
     bvh_traverse_packet(*T.bvh, p, res);
     for (int i = 0; i < PACKETSIZE; ++i) {
-        if (res.tri[i] < 0) { color[i] = BACKGROUND; continue; }
-        const Triangle& tri = T.bvh->tris[res.tri[i]];
+        if (!T.objects.empty()) {
+            Ray r{p.O[i], p.D[i], p.t[i]};
+            const int k = trace_objects(T, r);
+            if (k >= 0) { res.tri[i] = -2 - k; res.u[i] = 0; res.v[i] = 0; p.t[i] = r.t; }
+        }
+        if (res.tri[i] == -1) { color[i] = BACKGROUND; continue; }
         vec3 hit = p.O[i] + p.D[i] * p.t[i];
-        vec3 normal = tri.normal;
+        vec3 normal;
+        vec4 colorP;
+        SurfaceMaterial mat;
+        if (res.tri[i] >= 0) {
+            const Triangle& tri = T.bvh->tris[res.tri[i]];
+            normal = tri.normal;
+            colorP = tri_color(*T.bvh, tri, res.u[i], res.v[i]);
+            mat = {tri.refl, tri.refr, tri.rindex};
+        } else {
+            const Object& o = T.objects[-2 - res.tri[i]];
+            normal = object_normal(o, hit);
+            colorP = o.diffuse;
+            mat = {o.refl, o.refr, o.rindex};
+        }
         vec4 finalColor = {0, 0, 0, 0};
-        vec4 colorP = tri_color(*T.bvh, tri, res.u[i], res.v[i]);
-        direct_light(T, tri, hit, normal, colorP, finalColor);
+        direct_light(T, mat, hit, normal, colorP, finalColor);
         color[i] = vclamp(finalColor, 0.0f, 1.0f);
     }
 }
@@ -514,13 +634,28 @@ static void trace_packet(const Tracer& T, RayPacket& p, vec4* color, HitPacket& 
 static vec4 shade_recursive(const Tracer& T, Ray& a_Ray, int& a_ReflPass, int& a_RefrPass, float a_RIndex, HitRec* firstHit) {
     HitRec res{-1, 0, 0};
     int isHit = bvh_traverse(*T.bvh, a_Ray, res);
+    if (!T.objects.empty()) {
+        const int k = trace_objects(T, a_Ray);
+        if (k >= 0) { res = HitRec{-2 - k, 0, 0}; isHit = 1; }
+    }
     if (firstHit) *firstHit = res;
     if (!isHit) return BACKGROUND;
-    const Triangle& tri = T.bvh->tris[res.tri];
     vec3 hit = a_Ray.O + a_Ray.D * a_Ray.t;
-    vec3 normal = tri.normal;
+    vec3 normal;
+    vec4 colorP;
+    SurfaceMaterial tri;
+    if (res.tri >= 0) {
+        const Triangle& t = T.bvh->tris[res.tri];
+        normal = t.normal;
+        colorP = tri_color(*T.bvh, t, res.u, res.v);
+        tri = {t.refl, t.refr, t.rindex};
+    } else {
+        const Object& o = T.objects[-2 - res.tri];
+        normal = object_normal(o, hit);
+        colorP = o.diffuse;
+        tri = {o.refl, o.refr, o.rindex};
+    }
     vec4 finalColor = {0, 0, 0, 0};
-    vec4 colorP = tri_color(*T.bvh, tri, res.u, res.v);
     direct_light(T, tri, hit, normal, colorP, finalColor);
     if (tri.refl > 0.0f && a_ReflPass < MAXREFLPASSES) {
         a_ReflPass++;
@@ -599,6 +734,17 @@ static void render_tile(const Tracer& T, const Frame& f, int startx, int starty)
     if (g_ctr) g_ctr->primary_rays += PACKETSIZE;
     if (f.mode == 0) {
         trace_packet(T, p, color, res);
+    } else if (f.mode == 2) {
+        // BVH-depth view, first half (raytracer.cpp:581-586): the number of nodes the ray's traversal enters, kept as a
+        // bit pattern in the colour's first channel until the frame's maximum is known (ora_render)
+        for (i = 0; i < PACKETSIZE; ++i) {
+            Ray r{p.O[i], p.D[i], p.t[i]};
+            int depth = 0;
+            HitRec h{-1, 0, 0};
+            if (T.bvh->nTris != 0) traverse_depth(*T.bvh, 0, r, depth, h);
+            res.tri[i] = h.tri; res.u[i] = h.u; res.v[i] = h.v; p.t[i] = r.t;
+            f.fb[(startx + i % TILESIZE) + (starty + i / TILESIZE) * f.pitch] = (uint32_t)depth;
+        }
     } else {
         // the per-pixel loop the reference keeps at raytracer.cpp:474-489 (commented out there)
         for (i = 0; i < PACKETSIZE; ++i) {
@@ -612,7 +758,7 @@ static void render_tile(const Tracer& T, const Frame& f, int startx, int starty)
     i = 0;
     for (int y = starty; y < starty + TILESIZE; ++y)
         for (int x = startx; x < startx + TILESIZE; ++x) {
-            f.fb[x + y * f.pitch] = vec_to_pixel(color[i]);
+            if (f.mode != 2) f.fb[x + y * f.pitch] = vec_to_pixel(color[i]);
             if (f.hit_ids) f.hit_ids[x + (size_t)y * f.W] = res.tri[i];
             if (f.tuv) {
                 float* o = f.tuv + 3 * ((size_t)x + (size_t)y * f.W);
@@ -1269,8 +1415,29 @@ int ora_render(Context* c, const float* cam16, int W, int H, int mode, int spp_g
             fb[x + (size_t)y * pitch] = ((a[0] / n) << 24) | ((a[1] / n) << 16) | ((a[2] / n) << 8) | (a[3] / n);
         }
     }
+    if (mode == 2) {
+        // second half of the depth view: colour = clamp((1, depth / maxDepth, 1 - depth / maxDepth, 0)).  The reference
+        // divides by a running maximum that its worker threads update without synchronisation and that survives from
+        // frame to frame (raytracer.cpp:523, 584); its value once a static view has been rendered is the frame's maximum,
+        // which is what is used here for every pixel.
+        int maxDepth = 0;
+        for (int y = y_begin; y < y_end; ++y) for (int x = 0; x < W; ++x) maxDepth = std::max(maxDepth, (int)fb[x + (size_t)y * pitch]);
+        for (int y = y_begin; y < y_end; ++y) for (int x = 0; x < W; ++x) {
+            const int depth = (int)fb[x + (size_t)y * pitch];
+            const vec4 col = vclamp(vec4{1, (float)depth / maxDepth, 1.0f - (float)depth / maxDepth, 0}, 0.0f, 1.0f);
+            fb[x + (size_t)y * pitch] = vec_to_pixel(col);
+        }
+    }
     if (counters_out) memcpy(counters_out, &ctr, sizeof(ctr));
     return 0;
+}
+// the analytic primitives of the frame: n records of 13 floats {kind, pos.xyz, radius | dist, diffuse.xyzw, refl, refr, rindex}
+void ora_set_objects(Context* c, const float* rec13, int n) {
+    c->tracer.objects.clear();
+    for (int i = 0; i < n; ++i) {
+        const float* p = rec13 + 13 * i;
+        c->tracer.objects.push_back(Object{(int)p[0], {p[1], p[2], p[3]}, p[4], {p[5], p[6], p[7], p[8]}, p[9], p[10], p[11]});
+    }
 }
 // single rays, for known-answer checks: kind 0 = packet-of-one semantics is not defined, so
 // kind 0 = scalar traversal from the root WITHOUT the root gate, 1 = BVH::Traverse (with gate)

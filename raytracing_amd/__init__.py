@@ -5,4 +5,4 @@ container.  The compute path is HIP only -- importing this package never falls b
 implementation.
 """
 from . import binding, multigpu, scene_io  # noqa: F401
-from .binding import Camera, MrtError, Raytracer, MODE_PACKET, MODE_RECURSIVE  # noqa: F401
+from .binding import Camera, MrtError, Raytracer, MODE_PACKET, MODE_RECURSIVE, MODE_BVH_DEPTH  # noqa: F401

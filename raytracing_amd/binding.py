@@ -16,9 +16,10 @@ LIB_PATH = os.environ.get("MRT_LIB") or os.path.join(_HERE, "libmrt.so")     # M
 
 MODE_PACKET = 0
 MODE_RECURSIVE = 1
+MODE_BVH_DEPTH = 2
 
 SYMBOLS = ("mrt_create", "mrt_destroy", "mrt_last_error", "mrt_version", "mrt_scene_upload", "mrt_scene_upload_lbvh", "mrt_scene_refit",
-           "mrt_set_lights",
+           "mrt_set_lights", "mrt_set_objects",
            "mrt_bvh_build_host", "mrt_render", "mrt_host_alloc", "mrt_host_free", "mrt_render_submit", "mrt_render_wait", "mrt_render_device", "mrt_render_device_noalloc", "mrt_render_device_part", "mrt_part_rows",
            "mrt_raster_render", "mrt_raster_render_device", "mrt_trace_packets",
            "mrt_trace_rays", "mrt_get_ray_counts", "mrt_camera_look_at")
@@ -31,6 +32,11 @@ class MrtError(RuntimeError):
 class _Mesh(C.Structure):
     _fields_ = [("pos", C.c_void_p), ("uv", C.c_void_p), ("tri_normal", C.c_void_p), ("tri", C.c_void_p),
                 ("verts", C.c_int32), ("tris", C.c_int32), ("texture_id", C.c_int32),
+                ("refl", C.c_float), ("refr", C.c_float), ("rindex", C.c_float)]
+
+
+class _Object(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("pos", C.c_float * 3), ("param", C.c_float), ("diffuse", C.c_float * 4),
                 ("refl", C.c_float), ("refr", C.c_float), ("rindex", C.c_float)]
 
 
@@ -75,6 +81,7 @@ def lib():
         L.mrt_scene_upload_lbvh.argtypes = [vp, C.POINTER(_Mesh), i32, C.POINTER(_Texture), i32]
         L.mrt_scene_refit.argtypes = [vp, C.POINTER(_Mesh), i32]
         L.mrt_set_lights.argtypes = [vp, vp, i32]
+        L.mrt_set_objects.argtypes = [vp, C.POINTER(_Object), i32]
         L.mrt_bvh_build_host.argtypes = [C.POINTER(_Mesh), i32, vp, vp, vp, vp]
         L.mrt_render.argtypes = [vp, vp, C.c_uint32, vp, i32, vp]
         L.mrt_render_device.argtypes = [vp, vp, C.c_uint32, i32, i32, vp, i32, vp, vp]
@@ -229,6 +236,14 @@ class Raytracer:
     def set_lights(self, lights):
         a = np.ascontiguousarray(lights, np.float32).reshape(-1, 7)
         self._check(self.L.mrt_set_lights(self.h, _p(a), len(a)), "mrt_set_lights")
+
+    def set_objects(self, objects):
+        """Raytracer::m_Objects: rows of 13 floats {kind (0 sphere, 1 plane), pos.xyz, radius | dist, diffuse.xyzw, refl, refr, rindex}."""
+        a = np.ascontiguousarray(objects, np.float32).reshape(-1, 13)
+        arr = (_Object * max(1, len(a)))()
+        for i, r in enumerate(a):
+            arr[i] = _Object(int(r[0]), (C.c_float * 3)(*r[1:4]), float(r[4]), (C.c_float * 4)(*r[5:9]), float(r[9]), float(r[10]), float(r[11]))
+        self._check(self.L.mrt_set_objects(self.h, arr, len(a)), "mrt_set_objects")
 
     def render(self, cam, mode=MODE_PACKET, spp_grid=1, want_ids=True, fb=None, extra_flags=0):
         """Raytracer::Render(camera) into a host framebuffer; returns (fb, hit_ids)."""

@@ -41,6 +41,8 @@ struct SceneDev {
     const uint8_t* texels;
     const uint32_t* pal;
     const float4* lights;
+    const float4* objects;   // analytic primitives, 3 float4 each (kernels.hip: trace_objects); nullptr without any
+    int n_objects;
     int n_lights;
     int n_tris;
     int n_textures;

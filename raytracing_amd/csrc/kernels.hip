@@ -574,9 +574,77 @@ __device__ __forceinline__ Surf fetch_surface(const SceneDev& S, const Hit& h) {
     return s;
 }
 
+// ---------------------------------------------------------------------------------------
+// Analytic primitives: Sphere and Plane with the reference's Intersect / IsOccluded / HitNormal
+// (raytracer.cpp:146-213).  The reference keeps a list of them (raytracer.h:243) but never traces it; here they
+// join a frame like this: after the BVH has been searched every object is intersected in list order with the
+// ray's current t (so the nearest of triangles and objects wins, a triangle on an exact tie) and is reported as
+// id -2 - index; its surface is its HitNormal, its m_Diffuse as the colour and its own material scalars; a shadow
+// ray is blocked if the BVH blocks it or any object's IsOccluded says so.  Kernels are instantiated with
+// OBJ = true only for scenes that have objects, so frames without them run the code they always ran.
+// Records: [3k] = {pos.xyz | plane normal, radius | dist}, [3k+1] = diffuse (x=A,y=R,z=G,w=B),
+// [3k+2] = {refl, refr, rindex, bits(kind)}, kind 0 sphere, 1 plane.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void trace_objects(const SceneDev& S, f3 O, f3 D, float& t, Hit& h) {
+    for (int k = 0; k < S.n_objects; ++k) {
+        const float4 a = S.objects[3 * k];
+        const f3 pos = xyz(a);
+        bool hit = false;
+        float tn = 0.0f;
+        if (__float_as_uint(S.objects[3 * k + 2].w) == 0u) {      // Sphere::Intersect, raytracer.cpp:153-169
+            const f3 c = pos - O;
+            float tt = dot(c, D);
+            if (!(tt < 0.0f)) {
+                const f3 q = c - tt * D;
+                const float p2 = dot(q, q);
+                const float r2 = a.w * a.w;
+                if (!(p2 > r2)) {
+                    tt -= sqrtf(r2 - p2);
+                    hit = tt < t;
+                    tn = tt;
+                }
+            }
+        } else {                                                    // Plane::Intersect, raytracer.cpp:189-202
+            const float dnd = dot(pos, D);
+            if (!(dnd == 0.0f)) {
+                const float tt = -(dot(pos, O) + a.w) / dnd;
+                if (!(tt < 0.0f)) { hit = tt < t; tn = tt; }
+            }
+        }
+        if (hit) { t = tn; h.tri = -2 - k; h.u = 0.0f; h.v = 0.0f; }
+    }
+}
+__device__ __forceinline__ bool objects_occlude(const SceneDev& S, f3 O, f3 D) {
+    bool occluded = false;
+    for (int k = 0; k < S.n_objects; ++k) {
+        const float4 a = S.objects[3 * k];
+        const f3 pos = xyz(a);
+        if (__float_as_uint(S.objects[3 * k + 2].w) == 0u) {      // Sphere::IsOccluded, raytracer.cpp:170-180
+            const f3 c = pos - O;
+            const float tt = dot(c, D);
+            if (!(tt < 0.0f)) {
+                const f3 q = c - tt * D;
+                occluded = occluded || (dot(q, q) < a.w * a.w);
+            }
+        } else {                                                    // Plane::IsOccluded, raytracer.cpp:203-213
+            const float dnd = dot(pos, D);
+            if (!(dnd == 0)) occluded = occluded || !(-(dot(pos, O) + a.w) / dnd < 0.0f);
+        }
+    }
+    return occluded;
+}
+__device__ __forceinline__ Surf object_surface(const SceneDev& S, int k, f3 hit) {
+    const float4 a = S.objects[3 * k], d = S.objects[3 * k + 1], m = S.objects[3 * k + 2];
+    Surf s;
+    s.normal = __float_as_uint(m.w) == 0u ? (hit - xyz(a)) / a.w : xyz(a);      // HitNormal, raytracer.cpp:149-152, 185-188
+    s.refl = m.x; s.refr = m.y; s.rindex = m.z;
+    s.colorP = {d.x, d.y, d.z, d.w};
+    return s;
+}
+
 // Direct light of raytracer.cpp:551-570 / 604-623 for the lanes with `shade` set: one shadow
 // ray per light, starting exactly on the surface (no epsilon).  Must be called by all 64 lanes.
-template <class SC>
+template <bool OBJ, class SC>
 __device__ __forceinline__ void direct_light(const SC& sc, const SceneDev& S, bool shade, const Surf& s, f3 hit, f4& finalColor,
                                              int lane, uint32_t& n_shadow, Watch& wd) {
     const float lightStrength = shade ? 1.0f - (s.refr + s.refl) : 0.0f;
@@ -586,7 +654,8 @@ __device__ __forceinline__ void direct_light(const SC& sc, const SceneDev& S, bo
     for (int i = 0; i < S.n_lights; ++i) {
         const float4 lp = S.lights[2 * i], lc = S.lights[2 * i + 1];
         const f3 L = lit ? normalize(xyz(lp) - hit) : f3{0.0f, 0.0f, 1.0f};
-        const bool occluded = occluded_wave(sc, S.n_tris, S.coords_ok != 0, hit, L, lit, lane, wd);
+        bool occluded = occluded_wave(sc, S.n_tris, S.coords_ok != 0, hit, L, lit, lane, wd);
+        if constexpr (OBJ) { if (lit && !occluded) occluded = objects_occlude(S, hit, L); }
         if (lit) {
             ++n_shadow;
             if (!occluded) {
@@ -624,7 +693,7 @@ struct ShadeState {
     int stage;      // 0: reflection not tried yet, 1: refraction not tried yet, 2: done
 };
 
-template <class SC, typename STP>
+template <bool OBJ, class SC, typename STP>
 __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f3 O, f3 D, STP stack, int lane, Hit& primary,
                                               uint32_t& n_shadow, uint32_t& n_secondary, Watch& wd) {
     float frames[kFrames][kFrameWords];
@@ -642,16 +711,20 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
         bool isHit = false;
         MRT_PHASE_BEGIN(wd);
         if (tracing) isHit = traverse_nearest(sc, S.n_tris, S.coords_ok != 0, O, D, t, h, stack, wd);
+        if constexpr (OBJ) { if (tracing) { trace_objects(S, O, D, t, h); isHit = h.tri != -1; } }
         MRT_PHASE_END(wd, 16);
         if (tracing && first) { primary = h; first = false; }
         const bool shade = tracing && isHit;
         Surf s;
         s.normal = {0, 0, 1}; s.refl = 0; s.refr = 0; s.rindex = 1; s.colorP = {0, 0, 0, 0};
         f3 hit = O;
-        if (shade) { s = fetch_surface(S, h); hit = O + D * t; }
+        if (shade) {
+            hit = O + D * t;
+            if (!OBJ || h.tri >= 0) s = fetch_surface(S, h); else s = object_surface(S, -2 - h.tri, hit);
+        }
         f4 finalColor = {0, 0, 0, 0};
         MRT_PHASE_BEGIN(wd);
-        direct_light(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
+        direct_light<OBJ>(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
         MRT_PHASE_END(wd, 17);
         if (!tracing) continue;
         tracing = false;
@@ -734,7 +807,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // One tile: ray generation (threads.cpp:189-211), trace, shade, pixel pack + store
 // (threads.cpp:215-224).  MODE 0 = packet path, 1 = recursive shader.  All 64 lanes call it.
 // ---------------------------------------------------------------------------------------
-template <int MODE, class SC, typename STP>
+template <int MODE, bool OBJ, class SC, typename STP>
 __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, const FrameDev& F, int tile, int lane, STP stack) {
     const int ltr = tile / F.tiles_x, tx = tile - ltr * F.tiles_x;   // ltr: tile row within this launch
     int ty = F.tile_y0 + ltr;
@@ -762,16 +835,20 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
         const f3 rD = 1.0f / D;
         float t = 100000000;
         traverse_packet(sc, S.n_tris, O, D, rD, t, h, lane, wd);
-        const bool shade = h.tri >= 0;
+        if constexpr (OBJ) trace_objects(S, O, D, t, h);
+        const bool shade = h.tri != -1;
         Surf s;
         s.normal = {0, 0, 1}; s.refl = 0; s.refr = 0; s.rindex = 1; s.colorP = {0, 0, 0, 0};
         f3 hit = O;
-        if (shade) { s = fetch_surface(S, h); hit = O + D * t; }
+        if (shade) {
+            hit = O + D * t;
+            if (!OBJ || h.tri >= 0) s = fetch_surface(S, h); else s = object_surface(S, -2 - h.tri, hit);
+        }
         f4 finalColor = {0, 0, 0, 0};
-        direct_light(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
+        direct_light<OBJ>(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
         color = shade ? clamp01(finalColor) : MRT_BACKGROUND;
     } else {
-        color = shade_recursive(sc, S, O, D, stack, lane, h, n_shadow, n_secondary, wd);
+        color = shade_recursive<OBJ>(sc, S, O, D, stack, lane, h, n_shadow, n_secondary, wd);
     }
     const uint32_t px = vec_to_pixel(color);
 
@@ -800,7 +877,7 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
     }
 #endif
     if (F.stats) {
-        const uint32_t hits = (uint32_t)__popcll(__ballot(h.tri >= 0));
+        const uint32_t hits = (uint32_t)__popcll(__ballot(h.tri != -1));
         const uint32_t sh = wave_sum(n_shadow), se = wave_sum(n_secondary);
         if (lane == 0) {
             unsigned long long* slot = F.counters + kStatBase + 16 * (tile % kStatSlots);
@@ -816,13 +893,62 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// BVH-depth view (raytracer.cpp:581-586 with BVH::TraverseDepth :951-954 and BVHNode::TraverseDepth :1265-1326,
+// TEST 0 branch): a pixel shows how many nodes its primary ray's traversal enters.  That traversal is the
+// nearest-hit traversal with three differences: no root gate, a child box passes only with tFar > tNear
+// (strictly), and every node entered counts.  Per lane, true divisions, one node or one leaf per turn: a debug
+// view, written for clarity.
+// ---------------------------------------------------------------------------------------
+template <class SC, typename STP>
+__device__ __forceinline__ int traverse_depth(const SC& sc, int n_tris, f3 O, f3 D, float& t, Hit& h, STP stack, Watch& wd) {
+    h.tri = -1;
+    if (n_tris == 0) return 0;
+    int depth = 1, sp = 0;                     // the root is entered
+    uint32_t first = sc.node_first(0), count = sc.node_count(0);
+    bool alive = true;
+    while (alive) {
+        if (wd.expired(64)) break;
+        bool take_next = false;
+        if (count == 0) {
+            const uint32_t L = first, R = first + 1;
+            const v4f l0 = sc.node(2 * L), l1 = sc.node(2 * L + 1), r0 = sc.node(2 * R), r1 = sc.node(2 * R + 1);
+            float tNear, tFar, tNear2, tFar2;
+            slab_terms((xyz(l0) - O) / D, (xyz(l1) - O) / D, tNear, tFar);
+            slab_terms((xyz(r0) - O) / D, (xyz(r1) - O) / D, tNear2, tFar2);
+            const bool leftN = (tFar > tNear) && (tNear < t) && (tFar > 0);
+            const bool rightN = (tFar2 > tNear2) && (tNear2 < t) && (tFar2 > 0);
+            const bool go_right = rightN && (!leftN || tNear2 < tNear);
+            if (leftN && rightN) { stack[sp * 64] = go_right ? L : R; ++sp; }
+            if (leftN || rightN) {
+                first = go_right ? wbits(r0) : wbits(l0);
+                count = go_right ? wbits(r1) : wbits(l1);
+                ++depth;
+            } else take_next = true;
+        } else {
+            for (uint32_t k = first; k < first + count; ++k) tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
+            take_next = true;
+        }
+        if (take_next) {
+            if (sp == 0) alive = false;
+            else {
+                --sp;
+                const uint32_t n = stack[sp * 64];
+                first = sc.node_first(n); count = sc.node_count(n);
+                ++depth;
+            }
+        }
+    }
+    return depth;
+}
+
 __device__ __forceinline__ SceneGlobal global_scene(const SceneDev& S) {
     return SceneGlobal{reinterpret_cast<const v4f*>(S.nodes), reinterpret_cast<const v4f*>(S.triA),
                        reinterpret_cast<const v4f*>(S.triB), reinterpret_cast<const v2f*>(S.triC)};
 }
 
 // Scene in global memory: one 64-thread workgroup (one wave) per tile.  SD = stack entries.
-template <int MODE, int SD>
+template <int MODE, int SD, bool OBJ = false>
 #ifndef MRT_PACKET_WAVES
 #define MRT_PACKET_WAVES 8      // waves per SIMD the packet kernel is compiled for (register budget 512 / n)
 #endif
@@ -839,7 +965,56 @@ __global__ __launch_bounds__(64, MODE == 0 ? MRT_PACKET_WAVES : MRT_RECURSIVE_WA
     const int b = (int)blockIdx.x, q = b / kXcds;
     const int tile = ((q / kXcdRun) * kXcds + b % kXcds) * kXcdRun + q % kXcdRun;
     if (tile >= F.n_tiles) return;
-    render_tile<MODE>(global_scene(S), S, F, tile, lane, (MRT_LDS uint32_t*)lds_stack + lane);
+    render_tile<MODE, OBJ>(global_scene(S), S, F, tile, lane, (MRT_LDS uint32_t*)lds_stack + lane);
+}
+
+// First half of the depth view: one wave per tile writes every pixel's node count into the frame and folds the
+// frame's maximum into counters[6]; depth_colour_kernel then turns counts into colours.  The reference divides by
+// a running maximum that its worker threads update without synchronisation and that survives from frame to frame
+// (raytracer.cpp:523, 584); once a static view has been rendered that value is the frame's maximum, used here.
+template <int SD>
+__global__ __launch_bounds__(64) void depth_tiles_kernel(SceneDev S, FrameDev F) {
+    __shared__ uint32_t lds_stack[SD * 64];
+    const int lane = threadIdx.x, tile = (int)blockIdx.x;
+    if (tile >= F.n_tiles) return;
+    const int ty = tile / F.tiles_x, tx = tile - ty * F.tiles_x;
+    const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
+    const f3 p0 = {F.p0[0], F.p0[1], F.p0[2]}, d10 = {F.d10[0], F.d10[1], F.d10[2]}, d20 = {F.d20[0], F.d20[1], F.d20[2]};
+    const f3 O = {F.cam[0], F.cam[1], F.cam[2]};
+    const float u = (float)x * F.inv_w;
+    const float v = (float)y * F.inv_h;
+    const f3 planepos = (p0 + u * d10) + v * d20;
+    const f3 D = normalize(planepos - O);
+    Watch wd{watch_budget(S.n_node_slots, S.n_tris), F.counters + 5};
+    float t = 100000000;
+    Hit h;
+    h.u = 0; h.v = 0;
+    const int depth = traverse_depth(global_scene(S), S.n_tris, O, D, t, h, (MRT_LDS uint32_t*)lds_stack + lane, wd);
+    F.fb[(size_t)y * F.pitch + x] = (uint32_t)depth;
+    if (F.hit_ids) F.hit_ids[(size_t)y * F.width + x] = h.tri;
+    int m = depth;
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    const unsigned long long hits = (unsigned long long)__popcll(__ballot(h.tri >= 0));
+    if (lane == 0) {
+        atomicMax(&F.counters[6], (unsigned long long)m);
+        atomicAdd(&F.counters[kStatBase + 16 * (tile % kStatSlots)], 1ull | (hits << 32));     // primary rays and hits, as every frame kernel counts them
+    }
+}
+__global__ __launch_bounds__(256) void depth_colour_kernel(uint32_t* fb, int pitch, int W, int H, const unsigned long long* max_depth) {
+    const int x = (int)(blockIdx.x * 256 + threadIdx.x), y = (int)blockIdx.y;
+    if (x >= W || y >= H) return;
+    const int maxDepth = (int)*max_depth, depth = (int)fb[(size_t)y * pitch + x];
+    fb[(size_t)y * pitch + x] = vec_to_pixel(clamp01(f4{1.0f, (float)depth / maxDepth, 1.0f - (float)depth / maxDepth, 0.0f}));
+}
+hipError_t launch_depth_view(const SceneDev& S, const FrameDev& F, hipStream_t stream) {
+    if (F.n_tiles <= 0) return hipSuccess;
+    const dim3 grid((unsigned)F.n_tiles), block(64);
+    if (F.stack_entries <= 16) hipLaunchKernelGGL((depth_tiles_kernel<16>), grid, block, 0, stream, S, F);
+    else if (F.stack_entries <= 32) hipLaunchKernelGGL((depth_tiles_kernel<32>), grid, block, 0, stream, S, F);
+    else hipLaunchKernelGGL((depth_tiles_kernel<kStackDepth>), grid, block, 0, stream, S, F);
+    hipLaunchKernelGGL(depth_colour_kernel, dim3((unsigned)((F.width + 255) / 256), (unsigned)F.height), dim3(256), 0, stream,
+                       F.fb, F.pitch, F.width, F.height, (const unsigned long long*)(F.counters + 6));
+    return hipGetLastError();
 }
 
 // Scene resident in LDS: persistent workgroups of 16 waves copy nodes and triangles into LDS
@@ -898,7 +1073,7 @@ __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_t
         dry = 0;
         const int tile = F.tile_order ? (int)F.tile_order[pos] : pos;
         const unsigned long long t0 = __builtin_readcyclecounter();
-        render_tile<MODE>(sc, S, F, tile, lane, stack);
+        render_tile<MODE, false>(sc, S, F, tile, lane, stack);
         if (F.tile_cost && lane == 0) {
             const unsigned long long dt = __builtin_readcyclecounter() - t0;
             F.tile_cost[tile] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
@@ -1025,7 +1200,8 @@ template <int MODE>
 static hipError_t launch_global_mode(const SceneDev& S, const FrameDev& F, hipStream_t stream) {
     const int group = kXcds * kXcdRun;
     const dim3 grid((unsigned)((F.n_tiles + group - 1) / group * group)), block(64);
-    if (F.stack_entries <= 16) hipLaunchKernelGGL((render_tiles_global<MODE, 16>), grid, block, 0, stream, S, F);
+    if (S.n_objects > 0) hipLaunchKernelGGL((render_tiles_global<MODE, kStackDepth, true>), grid, block, 0, stream, S, F);
+    else if (F.stack_entries <= 16) hipLaunchKernelGGL((render_tiles_global<MODE, 16>), grid, block, 0, stream, S, F);
     else if (F.stack_entries <= 32) hipLaunchKernelGGL((render_tiles_global<MODE, 32>), grid, block, 0, stream, S, F);
     else hipLaunchKernelGGL((render_tiles_global<MODE, kStackDepth>), grid, block, 0, stream, S, F);
     return hipGetLastError();

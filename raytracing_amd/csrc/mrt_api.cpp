@@ -22,6 +22,7 @@
 namespace mrt {
 hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool resident, int n_cus, int resident_threads, hipStream_t stream);
 hipError_t prepare_render_kernels();
+hipError_t launch_depth_view(const SceneDev& S, const FrameDev& F, hipStream_t stream);
 hipError_t launch_order_tiles(const uint32_t* cost, uint32_t* packed, uint32_t* hist, uint32_t* order, int n, hipStream_t stream);
 size_t resident_lds_bytes(int n_node_slots, int n_tris, int stack_entries);
 hipError_t launch_trace_packets(const SceneDev& S, int n_packets, const float* O, const float* D, const float* rD,
@@ -118,6 +119,8 @@ struct mrt_ctx {
     DevBuf<uint8_t> d_texels;
     DevBuf<uint32_t> d_pal;
     std::vector<float4> lights;     // 2 per light
+    std::vector<float4> objects;    // 3 per analytic primitive (kernels.hip: trace_objects)
+    DevBuf<float4> d_objects;
     SceneDev scene{};
     // frame outputs of the synchronous entry points
     DevBuf<uint32_t> d_fb;
@@ -172,6 +175,8 @@ void refresh_scene_view(mrt_ctx* c) {
     S.nodes = c->d_nodes.p; S.triA = c->d_triA.p; S.triB = c->d_triB.p; S.triC = c->d_triC.p; S.attr = c->d_attr.p;
     S.tex = c->d_tex.p; S.texels = c->d_texels.p; S.pal = c->d_pal.p;
     S.lights = c->d_lights.p;
+    S.objects = c->objects.empty() ? nullptr : c->d_objects.p;
+    S.n_objects = (int)(c->objects.size() / 3);
     S.n_lights = (int)(c->lights.size() / 2);
     S.n_tris = (int)c->bvh.n_tris;
 }
@@ -202,7 +207,8 @@ int parse_flags(mrt_ctx* c, uint32_t flags, int& mode, int& g) {
     g = (int)((flags >> 8) & 0xffu);
     if (flags & ~(MRT_MODE_MASK | 0xff00u | MRT_FLAG_FRAME_ORDER | MRT_FLAG_NO_RAY_COUNTS)) return fail(c, MRT_E_ARG, "unknown render flag");
     if (g == 0) g = 1;
-    if (mode != (int)MRT_MODE_PACKET && mode != (int)MRT_MODE_RECURSIVE) return fail(c, MRT_E_ARG, "unknown render mode");
+    if (mode != (int)MRT_MODE_PACKET && mode != (int)MRT_MODE_RECURSIVE && mode != (int)MRT_MODE_BVH_DEPTH) return fail(c, MRT_E_ARG, "unknown render mode");
+    if (mode == (int)MRT_MODE_BVH_DEPTH && g != 1) return fail(c, MRT_E_ARG, "the BVH-depth view has no supersampling grid");
     if (g != 1 && g != 2 && g != 4 && g != 8) return fail(c, MRT_E_ARG, "supersampling grid must be 1, 2, 4 or 8");
     return MRT_OK;
 }
@@ -263,8 +269,20 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
     // The LDS-resident kernel pays off for the recursive shader, whose per-lane traversal reads a
     // different node or triangle in every lane.  The packet path reads wave-uniform data (scalar
     // loads through the scalar cache) and runs faster with one wave per tile at 8 waves per SIMD.
-    bool resident = c->resident && mode == (int)MRT_MODE_RECURSIVE;
-    if (env_int("MRT_RESIDENT_PACKET", 0)) resident = c->resident;
+    if (mode == (int)MRT_MODE_BVH_DEPTH) {
+        // colours are relative to the frame's deepest pixel, so the view is defined for whole frames only
+        if (share && share->n_parts > 1) return fail(c, MRT_E_ARG, "the BVH-depth view renders whole frames only");
+        if (y_begin != 0 || y_end != c->height) return fail(c, MRT_E_ARG, "the BVH-depth view renders whole frames only");
+        MRT_HIP(c, launch_depth_view(c->scene, F, stream));
+        MRT_HIP(c, hipEventRecord(c->last_done, stream));
+        c->last_stream = stream;
+        c->launched = true;
+        c->last_counters = F.counters;
+        c->last_n_lights = 0;
+        return MRT_OK;
+    }
+    bool resident = c->resident && mode == (int)MRT_MODE_RECURSIVE && c->scene.n_objects == 0;
+    if (env_int("MRT_RESIDENT_PACKET", 0)) resident = c->resident && c->scene.n_objects == 0;
     if (resident && F.n_tiles < (1 << 24) && !(flags & MRT_FLAG_FRAME_ORDER)) {
         // Launches of the same shape follow each other in a frame loop with a slowly moving camera:
         // start the tiles that were expensive last time first.
@@ -351,7 +369,7 @@ void mrt_destroy(mrt_ctx* c) {
     c->d_rayO.release(); c->d_rayD.release(); c->d_rayR.release(); c->d_rayT.release(); c->d_rayU.release(); c->d_rayV.release();
     c->d_rayTri.release(); c->d_rayFlag.release();
     c->d_nodes.release(); c->d_triA.release(); c->d_triB.release(); c->d_triC.release(); c->d_attr.release(); c->d_lights.release();
-    c->d_tex.release(); c->d_texels.release(); c->d_pal.release();
+    c->d_tex.release(); c->d_texels.release(); c->d_pal.release(); c->d_objects.release();
     c->d_fb.release(); c->d_ids.release(); c->d_counters.release();
     c->d_tile_cost.release(); c->d_tile_packed.release(); c->d_tile_order.release();
     raster_release(c->raster);
@@ -387,6 +405,27 @@ int mrt_set_lights(mrt_ctx* c, const float* pos_rgba7, int n) {
 
 enum class TreeSource { Reference, Lbvh, Refit };
 static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures, TreeSource source);
+
+int mrt_set_objects(mrt_ctx* c, const mrt_object* objects, int n) {
+    if (!c) return MRT_E_ARG;
+    if (n < 0 || (n > 0 && !objects)) return fail(c, MRT_E_ARG, "bad object array");
+    for (int i = 0; i < n; ++i)
+        if (objects[i].kind != MRT_OBJECT_SPHERE && objects[i].kind != MRT_OBJECT_PLANE) return fail(c, MRT_E_ARG, "unknown object kind");
+    MRT_HIP(c, hipSetDevice(c->device));
+    if (c->launched) MRT_HIP(c, hipEventSynchronize(c->last_done));       // a frame in flight may still read the old list
+    c->objects.clear();
+    for (int i = 0; i < n; ++i) {
+        const mrt_object& o = objects[i];
+        c->objects.push_back(make_float4(o.pos[0], o.pos[1], o.pos[2], o.param));
+        c->objects.push_back(make_float4(o.diffuse[0], o.diffuse[1], o.diffuse[2], o.diffuse[3]));
+        c->objects.push_back(make_float4(o.refl, o.refr, o.rindex, bits2f((uint32_t)o.kind)));
+    }
+    MRT_HIP(c, c->d_objects.upload(c->objects, c->stream));
+    MRT_HIP(c, hipStreamSynchronize(c->stream));
+    refresh_scene_view(c);
+    c->cost_shape = 0;
+    return MRT_OK;
+}
 
 int mrt_scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures) {
     return scene_upload(c, meshes, n_meshes, textures, n_textures, TreeSource::Reference);

@@ -3,7 +3,7 @@
 // reports frame time and ray throughput the way the reference's overlay does (game.cpp:95-112).
 //
 //   mrt_game [--scene assets/maze.obj | scene.mrts] [--size W H] [--frames N]
-//            [--mode packet|recursive|raster] [--pos x y z --lookat x y z]
+//            [--mode packet|recursive|depth|raster] [--spheres] [--pos x y z --lookat x y z]
 //            [--out frame.ppm|frame.png] [--out-sequence prefix] [--overlay] [--dump-scene out.mrts] [--device N]
 //            [--script "W*30 RIGHT*10 O*5 SPACE*1" --dt 0.016] [--no-render] [--pipeline]
 //            [--ranks N --rank R --nccl-id FILE [--block B] [--spp-grid G]]  |  [--rehearse-ranks N]
@@ -11,6 +11,8 @@
 // --script replays Game::HandleInput (game.cpp:41-75) without a keyboard: each token holds one key for N
 // frames of length dt (W S A D R F move, LEFT RIGHT UP DOWN turn, O P move the light, SPACE switches
 // between ray tracer and rasterizer).  --no-render runs the script only and prints the final state.
+// --mode depth is the BVH-depth view (raytracer.cpp:581-586; the script key T toggles it like game.cpp:73);
+// --spheres adds the two spheres Raytracer::Init creates (raytracer.cpp:404-412), which the reference never traces.
 // --overlay draws the reference's frame-time / FPS lines into every frame (game.cpp:95-112), updated once per second of
 // frame time like there; --out-sequence writes every frame as prefix_0000.png, prefix_0001.png, ... (the stand-in for the
 // window the reference presents its Surface in, template.cpp:111-127).
@@ -144,7 +146,7 @@ int main(int argc, char** argv) {
     MultiOpts multi;
     std::string scene_file = "assets/maze.obj", mode = "packet", out, dump, script;
     float dt = 0.016f;
-    bool no_render = false, pipeline = false, overlay = false;
+    bool no_render = false, pipeline = false, overlay = false, spheres = false;
     std::string sequence;
     int W = 800, H = 600, frames = 10, device = -1;       // game.h:3-4
     bool have_pose = false;
@@ -163,6 +165,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--no-render")) no_render = true;
         else if (!strcmp(argv[i], "--pipeline")) pipeline = true;
         else if (!strcmp(argv[i], "--overlay")) overlay = true;
+        else if (!strcmp(argv[i], "--spheres")) spheres = true;
         else if (!strcmp(argv[i], "--out-sequence")) { need(1); sequence = argv[++i]; }
         else if (!strcmp(argv[i], "--ranks")) { need(1); multi.ranks = atoi(argv[++i]); }
         else if (!strcmp(argv[i], "--rank")) { need(1); multi.rank = atoi(argv[++i]); }
@@ -213,12 +216,15 @@ int main(int argc, char** argv) {
         vec3 position = {0, 0, 0};                              // game.cpp:4, 33
         if (have_pose) { camera.SetPosition(pos); camera.LookAt(target); position = pos; }
         std::vector<float> light = {0, 5, 0, 1, 1, 1, 1};       // raytracer.cpp:396-399
-        bool is_raytracer = mode != "raster";
+        bool is_raytracer = mode != "raster", depth_view = mode == "depth";
         Raytracer raytracer;
         auto t0 = std::chrono::steady_clock::now();
         if (!no_render) {
             raytracer.Init(&screen, device);                    // game.cpp:17-18
             raytracer.BuildBVH(scene);                          // game.cpp:34
+            if (spheres)                                        // raytracer.cpp:404-412
+                raytracer.SetObjects({mrt_object{MRT_OBJECT_SPHERE, {1, 0, 0}, 0.5f, {1, 0, 1, 0}, 0.5f, 0.0f, 1.0f},
+                                      mrt_object{MRT_OBJECT_SPHERE, {-1, 0, 0}, 0.5f, {1, 1, 1, 1}, 0.0f, 0.5f, 1.5f}});
             printf("BuildBVH + upload: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         }
         auto add = [](vec3 a, vec3 b) { return vec3{a.x + b.x, a.y + b.y, a.z + b.z}; };
@@ -251,6 +257,7 @@ int main(int argc, char** argv) {
             if (!keys.empty()) {                                // Game::HandleInput, game.cpp:41-75
                 const std::string& k = keys[f];
                 if (k == "SPACE") is_raytracer = !is_raytracer;
+                if (k == "T") depth_view = !depth_view;         // game.cpp:73
                 if (k == "W") position = add(position, mul(mul(camera.GetForward(), dt), 10.0f));
                 if (k == "S") position = sub(position, mul(mul(camera.GetForward(), dt), 10.0f));
                 if (k == "D") position = add(position, mul(mul(camera.GetRight(), dt), 10.0f));
@@ -292,8 +299,9 @@ int main(int argc, char** argv) {
             screen.Clear(0);                                    // game.cpp:87
             t0 = std::chrono::steady_clock::now();
             if (!is_raytracer) raytracer.RenderRaster(camera);
+            else if (depth_view) raytracer.RenderDepth(camera);
             else if (mode == "recursive") raytracer.RenderRecursive(camera);
-            else if (mode == "packet" || mode == "raster") raytracer.Render(camera);
+            else if (mode == "packet" || mode == "raster" || mode == "depth") raytracer.Render(camera);
             else { fprintf(stderr, "unknown mode %s\n", mode.c_str()); return 2; }
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             if (f > 0 || frames == 1) { total_ms += ms; best_ms = ms < best_ms ? ms : best_ms; }

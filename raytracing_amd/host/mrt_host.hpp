@@ -488,6 +488,12 @@ public:
     void Render(const Camera& camera) { render(camera, MRT_MODE_PACKET); }
     // the per-pixel GetColorFromSphere loop the reference keeps commented out (raytracer.cpp:465-490)
     void RenderRecursive(const Camera& camera) { render(camera, MRT_MODE_RECURSIVE); }
+    // the BVH-depth view ('T' in game.cpp:73 toggles Raytracer::traverseDepth; raytracer.cpp:581-586)
+    void RenderDepth(const Camera& camera) { render(camera, MRT_MODE_BVH_DEPTH); }
+    // m_Objects (raytracer.h:243): spheres and planes traced next to the BVH
+    void SetObjects(const std::vector<mrt_object>& objects) {
+        check(mrt_set_objects(ctx_, objects.data(), (int)objects.size()), "mrt_set_objects");
+    }
     // Rasterizer::Render(camera) shares the context (the reference's rasterizer owns the scene)
     void RenderRaster(const Camera& camera) {
         check(mrt_raster_render(ctx_, camera.transform, screen_->GetBuffer(), screen_->GetPitch(), nullptr, nullptr), "mrt_raster_render");

@@ -171,6 +171,12 @@ class Oracle:
         return int(self.L.ora_nodehash(self.h))
 
     # ---- rendering ----
+    def set_objects(self, objects):
+        """Analytic primitives: rows of 13 floats {kind (0 sphere, 1 plane), pos.xyz, radius | dist, diffuse.xyzw, refl, refr, rindex, 0}."""
+        a = np.ascontiguousarray(objects, np.float32).reshape(-1, 13)
+        self.L.ora_set_objects.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        self.L.ora_set_objects(self.h, _p(a), len(a))
+
     def set_threads(self, n, pinned=False):
         """Worker threads of the tile pool; pinned=True keeps each on its own CPU (distinct physical cores first) and
         returns how many distinct cores they occupy (0: pinning refused by the system)."""

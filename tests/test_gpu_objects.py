@@ -1,0 +1,110 @@
+"""The reference's unused primitive types and its BVH-depth view on the GPU, against the oracle's restatement
+(raytracer.cpp:146-213, 581-586, 1265-1326).  The reference never traces its object list, so how objects join a
+frame is this build's definition (include/mrt.h, mrt_set_objects) and the oracle implements the same definition:
+parity here is HIP against oracle, not against recorded reference answers."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from conftest import POSES, colour_mismatch_fraction, pose_cam
+from raytracing_amd import MODE_BVH_DEPTH, MODE_PACKET, MODE_RECURSIVE, MrtError, Raytracer, scene_io
+
+pytestmark = pytest.mark.gpu
+
+# the two spheres Raytracer::Init creates (raytracer.cpp:404-412: a green half-mirror and white glass), lifted from y = 0 --
+# where the maze's walls hide them -- to y = 1.5, and a plane
+# {kind, pos.xyz, radius | dist, diffuse A R G B, refl, refr, rindex, pad}
+REFERENCE_SPHERES = np.float32([[0, 1, 1.5, 0, 0.5, 1, 0, 1, 0, 0.5, 0.0, 1.0, 0],
+                                [0, -1, 1.5, 0, 0.5, 1, 1, 1, 1, 0.0, 0.5, 1.5, 0]])
+PLANE = np.float32([[1, 0, 1, 0, 3.0, 0, 0.4, 0.5, 0.6, 0.2, 0.0, 1.0, 0]])
+
+
+def _pair(scene, W, H):
+    ora = oracle_lib.Oracle()
+    ora.add_scene(scene)
+    ora.build_bvh()
+    ora.set_threads(8)
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(scene)
+    return rt, ora
+
+
+@pytest.mark.parametrize("pose", POSES, ids=[p[0] for p in POSES])
+def test_bvh_depth_view_matches_oracle(maze_scene, maze_oracle, pose):
+    W = H = 256
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(maze_scene)
+    cam = pose_cam(pose)
+    fb, ids = rt.render(cam, mode=MODE_BVH_DEPTH)
+    ref = maze_oracle.render(cam, W, H, mode=MODE_BVH_DEPTH)
+    assert np.array_equal(ids, ref["ids"])
+    assert np.array_equal(fb, ref["fb"]), "%d pixels differ" % int((fb != ref["fb"]).sum())
+    assert (fb >> 24 == 0xFF).all() and (fb & 0xFF == 0).all()                                 # A = 1, B = 0
+    if pose[0] != "straight_down":              # (there every ray has a zero direction component and stops at the root: one colour)
+        assert len(np.unique(fb)) > 8
+    assert rt.ray_counts()["primary"] == W * H
+    with pytest.raises(MrtError, match="whole frames"):
+        import torch
+        t = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
+        rt.render_device(cam, t.data_ptr(), W, mode=MODE_BVH_DEPTH, rows=(0, 64))
+    with pytest.raises(MrtError, match="grid"):
+        rt.render(cam, mode=MODE_BVH_DEPTH, spp_grid=2)
+    rt.close()
+
+
+def test_bvh_depth_view_on_a_soup_and_an_empty_scene():
+    scene = scene_io.soup_scene(30000, seed=5)
+    rt, ora = _pair(scene, 192, 128)
+    for pose in (POSES[0], ("soup", (5, 1, 4), (0, 0, -20))):
+        cam = pose_cam(pose)
+        fb, ids = rt.render(cam, mode=MODE_BVH_DEPTH)
+        ref = ora.render(cam, 192, 128, mode=MODE_BVH_DEPTH)
+        assert np.array_equal(ids, ref["ids"]) and np.array_equal(fb, ref["fb"])
+    rt.close()
+
+
+@pytest.mark.parametrize("objects", [REFERENCE_SPHERES, np.concatenate([REFERENCE_SPHERES, PLANE])], ids=["two spheres", "spheres and plane"])
+def test_spheres_and_planes_match_oracle(maze_scene, objects):
+    W, H = 320, 192
+    rt, ora = _pair(maze_scene, W, H)
+    rt.set_objects(objects)
+    ora.set_objects(objects)
+    seen = set()
+    for pose in (POSES[0], POSES[1], ("high", (-5, 4, 8), (0, 1.5, 0)), ("close", (0, 1.6, 3), (0, 1.5, 0))):
+        cam = pose_cam(pose)
+        for mode in (MODE_PACKET, MODE_RECURSIVE):
+            fb, ids = rt.render(cam, mode=mode)
+            ref = ora.render(cam, W, H, mode=mode)
+            assert np.array_equal(ids, ref["ids"]), "mode %d pose %s: %d ids differ" % (mode, pose[0], int((ids != ref["ids"]).sum()))
+            assert colour_mismatch_fraction(fb, ref["fb"]) <= 0.001
+            if mode == MODE_PACKET:
+                assert np.array_equal(fb, ref["fb"])
+            seen |= set(np.unique(ids[ids < -1]).tolist())
+    assert {-2, -3} <= seen                                    # both spheres were actually hit somewhere
+    # without the list the frames are the plain scene's again
+    rt.set_objects(np.zeros((0, 13), np.float32))
+    ora.set_objects(np.zeros((0, 13), np.float32))
+    fb, ids = rt.render(pose_cam(POSES[1]), mode=MODE_RECURSIVE)
+    ref = ora.render(pose_cam(POSES[1]), W, H, mode=MODE_RECURSIVE)
+    assert np.array_equal(ids, ref["ids"]) and (ids >= -1).all() and colour_mismatch_fraction(fb, ref["fb"]) <= 0.001
+    with pytest.raises(MrtError, match="kind"):
+        bad = REFERENCE_SPHERES.copy()
+        bad[0, 0] = 7
+        rt.set_objects(bad)
+    rt.close()
+
+
+def test_objects_alone_have_the_analytic_answer():
+    """No triangles at all: a unit sphere straight ahead is hit where geometry says (t = 4 at the centre pixel)."""
+    scene = scene_io.soup_scene(1, seed=3)
+    scene["meshes"] = []
+    rt, ora = _pair(scene, 64, 64)
+    obj = np.float32([[0, 0, 0, -5, 1.0, 1, 0.2, 0.4, 0.6, 0.0, 0.0, 1.0, 0]])
+    rt.set_objects(obj)
+    ora.set_objects(obj)
+    for mode in (MODE_PACKET, MODE_RECURSIVE):
+        fb, ids = rt.render(oracle_lib.IDENTITY, mode=mode)
+        ref = ora.render(oracle_lib.IDENTITY, 64, 64, mode=mode, want_tuv=True)
+        assert np.array_equal(ids, ref["ids"]) and np.array_equal(fb, ref["fb"])
+        assert ids[32, 32] == -2 and ids[0, 0] == -1 and abs(ref["tuv"][32, 32, 0] - 4.0) < 1e-6
+    rt.close()

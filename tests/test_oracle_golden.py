@@ -187,3 +187,26 @@ def test_recursive_vs_packet_fraction_at_full_hd(maze_oracle, known):
     a = maze_oracle.render(oracle_lib.IDENTITY, 1920, 1080, mode=0, want_ids=False)["fb"]
     b = maze_oracle.render(oracle_lib.IDENTITY, 1920, 1080, mode=1, want_ids=False)["fb"]
     assert abs(float((a != b).mean()) - known["recursive_vs_packet_fraction"]["1920x1080_P0"]) < 0.0005
+
+
+def test_oracle_objects_and_depth_view_on_cpu(maze_oracle):
+    """The oracle's restatement of the reference's unused pieces: a unit sphere five units ahead is hit at t = 4 with
+    the normal pointing back at the eye, a plane below the eye at the distance geometry gives, and the BVH-depth view
+    of the maze has alpha 1, blue 0, red + green = 1 (to the quantisation) and its deepest pixel fully red."""
+    from raytracing_amd import scene_io
+    empty = scene_io.soup_scene(1, seed=3)
+    empty["meshes"] = []
+    o = oracle_lib.Oracle()
+    o.add_scene(empty)
+    o.build_bvh()
+    o.set_objects(np.float32([[0, 0, 0, -5, 1.0, 1, 0.2, 0.4, 0.6, 0.0, 0.0, 1.0, 0], [1, 0, 1, 0, 2.0, 0, 0.5, 0.5, 0.5, 0.0, 0.0, 1.0, 0]]))
+    o.set_lights(np.float32([[0, 0, 0, 1, 1, 1, 1]]))                 # a light at the eye: the sphere's centre is lit head on
+    for mode in (0, 1):
+        r = o.render(oracle_lib.IDENTITY, 64, 64, mode=mode, want_tuv=True)
+        assert r["ids"][32, 32] == -2 and abs(r["tuv"][32, 32, 0] - 4.0) < 1e-6
+        assert r["ids"][63, 32] == -3                                   # the plane y = -2, seen below the sphere
+        assert r["ids"][0, 0] == -1 and r["fb"][0, 0] == 0xFF4C4C4C
+    d = maze_oracle.render(oracle_lib.IDENTITY, 256, 128, mode=2)["fb"]
+    a, r_, g, b = d >> 24, (d >> 16) & 255, (d >> 8) & 255, d & 255
+    assert (a == 255).all() and (b == 0).all() and (np.abs(r_.astype(int) + g.astype(int) - 255) <= 1).all()
+    assert r_.max() == 255 and len(np.unique(r_)) > 8
