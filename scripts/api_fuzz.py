@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Random sequences of C-ABI calls on a few contexts (uploads of different scenes, both shaders, bands, interleaved
-shares, queued frames, rasterizer frames, light changes, context destruction) with every frame checked against a
+shares, queued frames, rasterizer frames (host and device), light changes, refits with moved vertices, object lists,
+the BVH-depth view, the entry point that allocates nothing, context destruction) with every frame checked against a
 frame rendered by a fresh context for the same scene, lights and camera.  Looks for state that leaks from one call
 into the next (tile order, cost history, pair buffer, queued-frame slots).  usage: api_fuzz.py [ops] [seed]"""
 import os
@@ -16,7 +17,7 @@ def main():
     n_ops = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     import torch
-    from raytracing_amd import Camera, Raytracer, scene_io, MODE_PACKET, MODE_RECURSIVE
+    from raytracing_amd import Camera, Raytracer, scene_io, MODE_PACKET, MODE_RECURSIVE, MODE_BVH_DEPTH
     from raytracing_amd.binding import HostFrame
     W, H = 320, 200
     maze = scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "maze.mrts"))
@@ -24,10 +25,40 @@ def main():
     for m in scenes["soup3k"]["meshes"]:
         m["refl"], m["refr"], m["rindex"] = 0.4, 0.3, 1.5
 
-    def fresh(scene_name, lights):
+    def moved(scene_name, variant):
+        """The scene with every vertex pushed along a fixed wave (variant 1 or 2); normals kept (only tracing parity matters here)."""
+        key = (scene_name, variant)
+        if key not in moved_cache:
+            sc = {"textures": scenes[scene_name]["textures"], "meshes": []}
+            for m in scenes[scene_name]["meshes"]:
+                pos = np.asarray(m["pos"], np.float32).reshape(-1, 3).copy()
+                pos[:, 1] += np.float32(0.05 * variant) * np.sin(pos[:, 0] * np.float32(1.7) + pos[:, 2]).astype(np.float32)
+                sc["meshes"].append(dict(m, pos=pos))
+            moved_cache[key] = sc
+        return moved_cache[key]
+    moved_cache = {}
+    no_objects = np.zeros((0, 13), np.float32)
+
+    def rand_objects():
+        n = int(rng.integers(0, 3))
+        o = np.zeros((n, 13), np.float32)
+        for i in range(n):
+            if rng.random() < 0.7:
+                o[i, :5] = [0, *rng.uniform(-6, 6, 3) * np.array([1, 0.2, 1]) + np.array([0, 1.5, -3]), rng.uniform(0.3, 1.5)]
+            else:
+                o[i, :5] = [1, 0, 1, 0, rng.uniform(0.5, 3)]
+            o[i, 5:9] = [0, *rng.uniform(0, 1, 3)]
+            o[i, 9:12] = [rng.choice([0, 0.4]), rng.choice([0, 0.3]), rng.choice([1.0, 1.5])]
+        return o
+
+    def fresh(scene_name, lights, variant=0, objects=no_objects):
         rt = Raytracer(W, H, device=0)
         rt.build_bvh(scenes[scene_name])
+        if variant:
+            rt.refit(moved(scene_name, variant))       # the same tree as the context under test: refit keeps the uploaded one
         rt.set_lights(lights)
+        if len(objects):
+            rt.set_objects(objects)
         return rt
 
     def rand_cam():
@@ -50,45 +81,75 @@ def main():
     refs = {}         # (scene name, lights bytes) -> fresh context for reference frames
     checked = 0
 
-    def reference(scene_name, lights):
-        key = (scene_name, lights.tobytes())
+    def reference(scene_name, lights, variant, objects):
+        key = (scene_name, lights.tobytes(), variant, objects.tobytes())
         if key not in refs:
             if len(refs) > 6:
                 refs.pop(next(iter(refs))).close()
-            refs[key] = fresh(scene_name, lights)
+            refs[key] = fresh(scene_name, lights, variant, objects)
         return refs[key]
 
     for op in range(n_ops):
         if not ctx or (len(ctx) < 3 and rng.random() < 0.15):
             name = str(rng.choice(list(scenes)))
             lights = rand_lights()
-            ctx.append([fresh(name, lights), name, lights])
+            ctx.append([fresh(name, lights), name, lights, 0, no_objects])
             continue
         k = int(rng.integers(0, len(ctx)))
-        rt, name, lights = ctx[k]
+        rt, name, lights, variant, objects = ctx[k]
         what = rng.random()
         cam = rand_cam()
         mode = MODE_RECURSIVE if rng.random() < 0.6 else MODE_PACKET
-        ref = reference(name, lights)
-        if what < 0.08:
+        ref = reference(name, lights, variant, objects)
+        if what < 0.06:
             rt.close()
             ctx.pop(k)
-        elif what < 0.16:
+        elif what < 0.12:
             name = str(rng.choice(list(scenes)))
             rt.build_bvh(scenes[name])
-            ctx[k][1] = name
-        elif what < 0.24:
+            ctx[k][1], ctx[k][3] = name, 0            # a new upload; lights and objects stay with the context
+        elif what < 0.18:
             lights = rand_lights()
             rt.set_lights(lights)
             ctx[k][2] = lights
-        elif what < 0.50:
+        elif what < 0.24:
+            variant = int(rng.integers(1, 3))
+            rt.refit(moved(name, variant))
+            ctx[k][3] = variant
+        elif what < 0.29:
+            objects = rand_objects()
+            rt.set_objects(objects)
+            ctx[k][4] = objects
+        elif what < 0.34:
+            fb, ids = rt.render(cam, mode=MODE_BVH_DEPTH)
+            fb2, ids2 = ref.render(cam, mode=MODE_BVH_DEPTH)
+            assert np.array_equal(fb, fb2) and np.array_equal(ids, ids2), "op %d: depth view differs" % op
+            checked += 1
+        elif what < 0.40:
+            d = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+            di = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+            rt.render_device_noalloc(cam, d.data_ptr(), W, mode=mode, ids_ptr=di.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            counts = rt.ray_counts()
+            fb2, ids2 = ref.render(cam, mode=mode)
+            assert np.array_equal(d.cpu().numpy().view(np.uint32), fb2) and np.array_equal(di.cpu().numpy(), ids2), "op %d: no-alloc frame differs" % op
+            assert counts == ref.ray_counts(), "op %d: ray counters of the no-alloc frame differ" % op
+            checked += 1
+        elif what < 0.44:
+            d = torch.full((H, W), 0x123456, dtype=torch.int32, device="cuda")
+            rt.raster_device(cam, d.data_ptr(), W, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            want = ref.raster(cam, fb=np.full((H, W), 0x123456, np.uint32))[0]
+            assert np.array_equal(d.cpu().numpy().view(np.uint32), want), "op %d: device rasterizer frame differs" % op
+            checked += 1
+        elif what < 0.58:
             g = 2 if rng.random() < 0.25 else 1
             fb, ids = rt.render(cam, mode=mode, spp_grid=g)
             fb2, ids2 = ref.render(cam, mode=mode, spp_grid=g)
             assert np.array_equal(fb, fb2) and np.array_equal(ids, ids2), "op %d: render differs" % op
             assert rt.ray_counts() == ref.ray_counts(), "op %d: ray counters differ" % op
             checked += 1
-        elif what < 0.62:
+        elif what < 0.68:
             y0 = 8 * int(rng.integers(0, H // 8))
             y1 = 8 * int(rng.integers(y0 // 8 + 1, H // 8 + 1))
             d = torch.zeros((H, W), dtype=torch.int32, device="cuda")
@@ -99,7 +160,7 @@ def main():
             fb2, _ = ref.render(cam, mode=mode)
             assert np.array_equal(d.cpu().numpy().view(np.uint32)[y0:y1], fb2[y0:y1]), "op %d: band differs" % op
             checked += 1
-        elif what < 0.72:
+        elif what < 0.76:
             n_parts = int(rng.integers(2, 5))
             d = torch.zeros((H, W), dtype=torch.int32, device="cuda")
             for p in rng.permutation(n_parts):
@@ -109,7 +170,7 @@ def main():
             fb2, _ = ref.render(cam, mode=mode)
             assert np.array_equal(d.cpu().numpy().view(np.uint32), fb2), "op %d: interleaved shares differ" % op
             checked += 1
-        elif what < 0.86:
+        elif what < 0.88:
             n = int(rng.integers(1, 5))
             cams = [rand_cam() for _ in range(n)]
             frames = [HostFrame(H, W) for _ in range(n)]
