@@ -65,7 +65,8 @@ struct FrameDev {
     int grid_g;              // supersampling grid g: 1, 2, 4 or 8
     int pitch;               // output row pitch in pixels
     int stack_entries;       // per-ray traversal stack entries this BVH needs (depth + 2)
-    int stats;               // accumulate the ray counters [0..3] (four atomics per tile)
+    int stats;               // accumulate the ray counters
+    int n_queues;            // tile queues of the persistent kernel (set by its launcher: at most one per workgroup)
     uint32_t* fb;            // output frame (output resolution)
     int32_t* hit_ids;        // optional, traced-image resolution
     // counters[0..15]: [5] watchdog code.  counters[kQueueBase + 16*q]: next index of tile queue q

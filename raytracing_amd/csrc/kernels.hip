@@ -1055,22 +1055,23 @@ __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_t
     MRT_LDS uint16_t* stack = l_stacks + (size_t)wave * F.stack_entries * 64 + lane;
     // Tile queue.  One shared counter would serialise every pull of every wave on one address
     // (tens of thousands of returning atomics per frame); instead the tiles are dealt round-robin
-    // into kTileQueues queues, each with its own counter on its own cache line.  A workgroup
-    // starts on queue (blockIdx % kTileQueues) and moves on to the next queue when one runs dry,
-    // so all tiles are drawn exactly once whatever the placement of the workgroups.
+    // into F.n_queues queues, each with its own counter on its own cache line.  Workgroup b draws
+    // from queue b % n_queues only and its waves leave when that queue runs dry; the launcher never
+    // makes more queues than workgroups, so every queue has a workgroup that drains it and all tiles
+    // are drawn exactly once whatever the placement of the workgroups.  (Letting a wave move on to
+    // the other queues before it leaves cost 2 % of the headline frame: the last wave of the frame
+    // ended with one failed pull per queue, back to back, each a round trip to memory.)
     // (Measured and dropped: pulling the next tile while the current one renders, which hides the pull's
     // round trip to the L2 -- 8 % slower, because with the expensive tiles handed out first a tile reserved
-    // early waits behind an expensive one; and finding the next queue with tiles by reading all counters at
-    // once instead of one failed pull per dry queue -- 2 % slower.)
-    const int n_queues = F.n_tiles < kTileQueues ? 1 : kTileQueues;
-    int q = (int)(blockIdx.x % (unsigned)n_queues), dry = 0;
-    for (int pulls = 0; pulls <= F.n_tiles + n_queues && dry < n_queues; ++pulls) {   // bounded: no wave can draw more
+    // early waits behind an expensive one.)
+    const int n_queues = F.n_queues;
+    const int q = (int)(blockIdx.x % (unsigned)n_queues);
+    for (int pulls = 0; pulls <= F.n_tiles; ++pulls) {   // bounded: no wave can draw more
         unsigned long long next = 0;
         if (lane == 0) next = atomicAdd(&F.counters[kQueueBase + 16 * q], 1ull);
         const int idx = __builtin_amdgcn_readfirstlane((int)next);
-        const int pos = idx * n_queues + q;
-        if (pos >= F.n_tiles) { q = (q + 1 == n_queues) ? 0 : q + 1; ++dry; continue; }
-        dry = 0;
+        const long long pos = (long long)idx * n_queues + q;
+        if (pos >= (long long)F.n_tiles) break;
         const int tile = F.tile_order ? (int)F.tile_order[pos] : pos;
         const unsigned long long t0 = __builtin_readcyclecounter();
         render_tile<MODE, false>(sc, S, F, tile, lane, stack);
@@ -1213,7 +1214,9 @@ static hipError_t launch_resident_mode(const SceneDev& S, const FrameDev& F, int
     threads = std::max(64, std::min(kResidentThreads, threads / 64 * 64));
     const int waves = threads / 64;
     const int blocks = std::max(1, std::min(n_cus, (F.n_tiles + waves - 1) / waves));
-    hipLaunchKernelGGL((render_tiles_resident<MODE>), dim3((unsigned)blocks), dim3((unsigned)threads), lds, stream, S, F);
+    FrameDev Fq = F;
+    Fq.n_queues = std::min(kTileQueues, blocks);          // every queue needs a workgroup of its own: nobody else drains it
+    hipLaunchKernelGGL((render_tiles_resident<MODE>), dim3((unsigned)blocks), dim3((unsigned)threads), lds, stream, S, Fq);
     return hipGetLastError();
 }
 
