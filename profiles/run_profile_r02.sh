@@ -11,6 +11,11 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu > $OUT/trace_stdout.log 2>&1 || { echo "trace run failed"; tail -5 $OUT/trace_stdout.log; exit 1; }
 echo "trace done"
+# the headline alone (no sub-benchmarks): the average duration of its kernel in this trace is the one to compare with
+# bench.py's roofline.kernel_ms
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_headline -o trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu --no-extra > $OUT/trace_headline_stdout.log 2>&1 || { echo "headline trace run failed"; tail -5 $OUT/trace_headline_stdout.log; exit 1; }
+echo "headline trace done"
+[ "${2:-}" = "trace-only" ] && exit 0
 pass() {  # config, pass name, counters...
   local cfg=$1 name=$2; shift 2
   timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_${cfg}_$name -o pmc -- python3 $GRAFT_REPO_ROOT/scripts/config_probe.py $cfg 3 > $OUT/pmc_${cfg}_${name}_stdout.log 2>&1 || { echo "pmc pass $cfg $name failed"; tail -3 $OUT/pmc_${cfg}_${name}_stdout.log; return 1; }

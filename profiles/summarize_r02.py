@@ -19,7 +19,7 @@ DOMINANT = {"c2": "render_tiles_resident<1>", "c2p": "render_tiles_global<0, 16>
 
 
 def short(name):
-    return name.replace("void mrt::", "").replace("mrt::", "").split("(")[0]
+    return name.replace("void mrt::", "").replace("mrt::", "").split("(")[0].replace(", false>", ">")
 
 
 def main():
@@ -28,6 +28,9 @@ def main():
     dst = os.path.join(ROOT, "profiles", tag)
     os.makedirs(dst, exist_ok=True)
     shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
+    headline = os.path.join(src, "trace_headline", "trace_kernel_stats.csv")
+    if os.path.exists(headline):
+        shutil.copy(headline, os.path.join(dst, "kernel_stats_headline.csv"))
     summary = {}
     for d in sorted(glob.glob(os.path.join(src, "pmc_*_*", "pmc_counter_collection.csv"))):
         cfg = os.path.basename(os.path.dirname(d)).split("_")[1]
