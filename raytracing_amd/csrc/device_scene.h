@@ -82,6 +82,11 @@ struct FrameDev {
     // expensive tiles of the previous launch first; the queues hand tiles out in that order.
     uint32_t* tile_cost;
     const uint32_t* tile_order;
+    // The scene relative to this frame's eye, for the packet traversal of the primary rays (kernels.hip:
+    // SceneGlobalEye, eye_relative_kernel); set for every packet-path launch of the one-wave-per-tile kernel.
+    const float4* eye_nodes;
+    const float4* eye_t;
+    const float4* eye_q;
 };
 
 constexpr int kStatSlots = 256;

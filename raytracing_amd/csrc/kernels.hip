@@ -96,6 +96,7 @@ struct Watch {
 // ---------------------------------------------------------------------------------------
 struct SceneGlobal {
     static constexpr bool kPrefetchLeaf = false;
+    static constexpr bool kEyeRelative = false;
     const v4f* nodes; const v4f* triA; const v4f* triB; const v2f* triC;
     __device__ __forceinline__ v4f node(uint32_t i) const { return nodes[i]; }
     __device__ __forceinline__ v4f tri_a(uint32_t k) const { return triA[k]; }
@@ -106,8 +107,22 @@ struct SceneGlobal {
     __device__ __forceinline__ uint32_t node_first(uint32_t n) const { return __float_as_uint(reinterpret_cast<const float*>(nodes)[8 * n + 3]); }
     __device__ __forceinline__ uint32_t node_count(uint32_t n) const { return __float_as_uint(reinterpret_cast<const float*>(nodes)[8 * n + 7]); }
 };
+// The scene as the frame's primary rays see it.  All primary rays start at the eye, so everything the packet
+// traversal computes from the origin and the scene alone is the same for every ray of every tile:
+// bound - O of the box tests (raytracer.cpp:1408-1409) and, of the triangle test (raytracer.cpp:287-356),
+// tvec = O - p0, qvec = cross(tvec, e1) and the numerator dot(e2, qvec).  eye_relative_kernel evaluates them
+// once per frame with the same operations in the same order; the packet traversal of the frame kernel reads
+// them (scalar loads, like the nodes and triangles themselves) instead of issuing those subtractions,
+// the cross product and the dot product in every wave:
+//   eyeNodes[2i], [2i+1] = {min - O, bits(firstLeft)}, {max - O, bits(count)}
+//   eyeT[k] = {tvec.xyz, dot(e2, qvec)}      eyeQ[k] = {qvec.xyz, bits(triangle id)}
+struct SceneGlobalEye : SceneGlobal {
+    static constexpr bool kEyeRelative = true;
+    const v4f* eyeNodes; const v4f* eyeT; const v4f* eyeQ;
+};
 struct SceneLds {
     static constexpr bool kPrefetchLeaf = true;     // request triangle k+1 before testing triangle k
+    static constexpr bool kEyeRelative = false;
     MRT_LDS const v4f* nodes; MRT_LDS const v4f* triA; MRT_LDS const v4f* triB; MRT_LDS const v2f* triC;
     __device__ __forceinline__ v4f node(uint32_t i) const { return nodes[i]; }
     __device__ __forceinline__ v4f tri_a(uint32_t k) const { return triA[k]; }
@@ -214,27 +229,9 @@ __device__ __forceinline__ bool slab_pair_shadow_interval(v4f l0, v4f l1, v4f r0
     return (leftN || l_no) && (rightN || r_no);
 }
 
-// ---------------------------------------------------------------------------------------
-// Ray/triangle: Triangle::Intersect / Intersect2 (raytracer.cpp:287-356).
-// WAVE_REJECT: the lanes calling this test the SAME triangle (packet leaves, shared shadow
-// traversal).  The exact test needs a correctly rounded 1/det; a hardware reciprocal
-// estimate is enough to see that a ray misses by a clear margin, and the exact division is
-// issued only when some lane cannot be ruled out that way.
-// ---------------------------------------------------------------------------------------
+// Second half of the triangle test: from the determinant and the three numerators to the running hit.
 template <bool WAVE_REJECT>
-__device__ __forceinline__ void tri_test(v4f A, v4f B, v2f C, f3 O, f3 D, float& t, Hit& h, Watch& wd) {
-    const f3 e1 = {A.x, A.y, A.z}, e2 = {A.w, B.x, B.y}, p0 = {B.z, B.w, C.x};
-    const f3 pvec = cross(D, e2);
-    const float det = dot(e1, pvec);
-    if (WAVE_REJECT) {
-        if (!__any(!(det < -kEpsilon))) return;          // back-facing for every ray of the wave
-    }
-    MRT_TICK(wd, WAVE_REJECT ? 6 : 12);
-    const f3 tvec = O - p0;
-    const float un = dot(tvec, pvec);
-    const f3 qvec = cross(tvec, e1);
-    const float vn = dot(D, qvec);
-    const float tn = dot(e2, qvec);
+__device__ __forceinline__ void tri_decide(float det, float un, float vn, float tn, uint32_t id, float& t, Hit& h, Watch& wd) {
     if (WAVE_REJECT) {
         constexpr float m = 1e-5f;      // far above the 2^-22 relative error of estimate * numerator
         const float rc = __builtin_amdgcn_rcpf(det);
@@ -260,9 +257,45 @@ __device__ __forceinline__ void tri_test(v4f A, v4f B, v2f C, f3 O, f3 D, float&
     const float T = tn * invDet;
     live = live && !(T < 0.0f) && (T < t);
     t = live ? T : t;
-    h.tri = live ? (int)__float_as_uint(C.y) : h.tri;
+    h.tri = live ? (int)id : h.tri;
     h.u = live ? u : h.u;
     h.v = live ? v : h.v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Ray/triangle: Triangle::Intersect / Intersect2 (raytracer.cpp:287-356).
+// WAVE_REJECT: the lanes calling this test the SAME triangle (packet leaves, shared shadow
+// traversal).  The exact test needs a correctly rounded 1/det; a hardware reciprocal
+// estimate is enough to see that a ray misses by a clear margin, and the exact division is
+// issued only when some lane cannot be ruled out that way.
+// ---------------------------------------------------------------------------------------
+template <bool WAVE_REJECT>
+__device__ __forceinline__ void tri_test(v4f A, v4f B, v2f C, f3 O, f3 D, float& t, Hit& h, Watch& wd) {
+    const f3 e1 = {A.x, A.y, A.z}, e2 = {A.w, B.x, B.y}, p0 = {B.z, B.w, C.x};
+    const f3 pvec = cross(D, e2);
+    const float det = dot(e1, pvec);
+    if (WAVE_REJECT) {
+        if (!__any(!(det < -kEpsilon))) return;          // back-facing for every ray of the wave
+    }
+    MRT_TICK(wd, WAVE_REJECT ? 6 : 12);
+    const f3 tvec = O - p0;
+    const float un = dot(tvec, pvec);
+    const f3 qvec = cross(tvec, e1);
+    const float vn = dot(D, qvec);
+    const float tn = dot(e2, qvec);
+    tri_decide<WAVE_REJECT>(det, un, vn, tn, __float_as_uint(C.y), t, h, wd);
+}
+
+// The same test for a ray that starts at the eye, from the frame's precomputed terms (SceneGlobalEye).
+__device__ __forceinline__ void tri_test_eye(v4f A, v2f Blo, v4f T, v4f Q, f3 D, float& t, Hit& h, Watch& wd) {
+    const f3 e1 = {A.x, A.y, A.z}, e2 = {A.w, Blo.x, Blo.y};
+    const f3 pvec = cross(D, e2);
+    const float det = dot(e1, pvec);
+    if (!__any(!(det < -kEpsilon))) return;
+    MRT_TICK(wd, 6);
+    const float un = dot(f3{T.x, T.y, T.z}, pvec);
+    const float vn = dot(D, f3{Q.x, Q.y, Q.z});
+    tri_decide<true>(det, un, vn, T.w, __float_as_uint(Q.w), t, h, wd);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -304,9 +337,19 @@ struct LaneStack3 {
 // ---------------------------------------------------------------------------------------
 template <bool FINITE, class SC>
 __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f3 rD, float& t, Hit& h, int lane, Watch& wd) {
+    // box(i): node record i as the box tests want it; with the frame's eye-relative copy the subtraction of
+    // the origin has already been done
+    auto box = [&](uint32_t i) -> v4f {
+        if constexpr (SC::kEyeRelative) return sc.eyeNodes[i]; else return sc.node(i);
+    };
     auto terms = [&](f3 bmin, f3 bmax, float& tn, float& tf) {
-        if (FINITE) slab_terms_finite((bmin - O) * rD, (bmax - O) * rD, tn, tf);
-        else slab_terms((bmin - O) * rD, (bmax - O) * rD, tn, tf);
+        if constexpr (SC::kEyeRelative) {
+            if (FINITE) slab_terms_finite(bmin * rD, bmax * rD, tn, tf);
+            else slab_terms(bmin * rD, bmax * rD, tn, tf);
+        } else {
+            if (FINITE) slab_terms_finite((bmin - O) * rD, (bmax - O) * rD, tn, tf);
+            else slab_terms((bmin - O) * rD, (bmax - O) * rD, tn, tf);
+        }
     };
     LaneStack1 work;
     work.push(lane, 0u);                       // scan(root, f = 0): raytracer.cpp:1351-1357
@@ -316,7 +359,7 @@ __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f
         const uint32_t e = work.pop();
         uint32_t node = e >> 6;
         const int f = (int)(e & 63u);
-        const v4f n0 = sc.node(2 * node), n1 = sc.node(2 * node + 1);
+        const v4f n0 = box(2 * node), n1 = box(2 * node + 1);
         float tn, tf;
         terms(xyz(n0), xyz(n1), tn, tf);
         const bool pass = slab_pass(tn, tf, t);
@@ -327,7 +370,12 @@ __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f
         for (;;) {                             // visit(node = {first,count}, firstActive = i)
             if (count != 0) {
                 if (lane >= i) {
-                    if constexpr (SC::kPrefetchLeaf) {
+                    if constexpr (SC::kEyeRelative) {
+                        for (uint32_t k = first; k < first + count; ++k) {
+                            MRT_TICK(wd, 10);
+                            tri_test_eye(sc.tri_a(k), sc.tri_b_lo(k), sc.eyeT[k], sc.eyeQ[k], D, t, h, wd);
+                        }
+                    } else if constexpr (SC::kPrefetchLeaf) {
                         v4f A = sc.tri_a(first), B = sc.tri_b(first);
                         v2f C = sc.tri_c(first);
                         const uint32_t last = first + count - 1;
@@ -350,7 +398,7 @@ __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f
             }
             MRT_TICK(wd, 9);
             const uint32_t L = first, R = first + 1;
-            const v4f l0 = sc.node(2 * L), l1 = sc.node(2 * L + 1), r0 = sc.node(2 * R), r1 = sc.node(2 * R + 1);
+            const v4f l0 = box(2 * L), l1 = box(2 * L + 1), r0 = box(2 * R), r1 = box(2 * R + 1);
             float tnl, tfl, tnr, tfr;
             terms(xyz(l0), xyz(l1), tnl, tfl);
             terms(xyz(r0), xyz(r1), tnr, tfr);
@@ -965,7 +1013,35 @@ __global__ __launch_bounds__(64, MODE == 0 ? MRT_PACKET_WAVES : MRT_RECURSIVE_WA
     const int b = (int)blockIdx.x, q = b / kXcds;
     const int tile = ((q / kXcdRun) * kXcds + b % kXcds) * kXcdRun + q % kXcdRun;
     if (tile >= F.n_tiles) return;
-    render_tile<MODE, OBJ>(global_scene(S), S, F, tile, lane, (MRT_LDS uint32_t*)lds_stack + lane);
+    if constexpr (MODE == 0) {
+        const SceneGlobalEye sc{global_scene(S), reinterpret_cast<const v4f*>(F.eye_nodes), reinterpret_cast<const v4f*>(F.eye_t),
+                                reinterpret_cast<const v4f*>(F.eye_q)};
+        render_tile<MODE, OBJ>(sc, S, F, tile, lane, (MRT_LDS uint32_t*)lds_stack + lane);
+    } else {
+        render_tile<MODE, OBJ>(global_scene(S), S, F, tile, lane, (MRT_LDS uint32_t*)lds_stack + lane);
+    }
+}
+
+// The frame's eye-relative copy of the nodes and triangles (SceneGlobalEye): one thread per node record and
+// per triangle, the operations of the box and triangle tests in their order.
+__global__ __launch_bounds__(256) void eye_relative_kernel(SceneDev S, float ox, float oy, float oz, float4* eye_nodes, float4* eye_t, float4* eye_q) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const f3 O = {ox, oy, oz};
+    if (i < 2u * (uint32_t)S.n_node_slots) {
+        const float4 n = S.nodes[i];
+        const f3 d = f3{n.x, n.y, n.z} - O;
+        eye_nodes[i] = make_float4(d.x, d.y, d.z, n.w);
+    }
+    if (i < (uint32_t)S.n_tris) {
+        const float4 A = S.triA[i], B = S.triB[i];
+        const float2 C = S.triC[i];
+        const f3 e1 = {A.x, A.y, A.z}, e2 = {A.w, B.x, B.y}, p0 = {B.z, B.w, C.x};
+        const f3 tvec = O - p0;
+        const f3 qvec = cross(tvec, e1);
+        const float tn = dot(e2, qvec);
+        eye_t[i] = make_float4(tvec.x, tvec.y, tvec.z, tn);
+        eye_q[i] = make_float4(qvec.x, qvec.y, qvec.z, C.y);
+    }
 }
 
 // First half of the depth view: one wave per tile writes every pixel's node count into the frame and folds the
@@ -1234,6 +1310,13 @@ hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool re
     if (F.n_tiles <= 0) return hipSuccess;
     if (resident) return mode == 0 ? launch_resident_mode<0>(S, F, n_cus, resident_threads, stream) : launch_resident_mode<1>(S, F, n_cus, resident_threads, stream);
     return mode == 0 ? launch_global_mode<0>(S, F, stream) : launch_global_mode<1>(S, F, stream);
+}
+
+hipError_t launch_eye_relative(const SceneDev& S, const float eye[3], float4* eye_nodes, float4* eye_t, float4* eye_q, hipStream_t stream) {
+    const uint32_t n = std::max(2u * (uint32_t)S.n_node_slots, (uint32_t)S.n_tris);
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(eye_relative_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, S, eye[0], eye[1], eye[2], eye_nodes, eye_t, eye_q);
+    return hipGetLastError();
 }
 
 // flag: one device word, zero on entry; a traversal that exhausts its loop budget leaves a code in it

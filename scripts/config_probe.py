@@ -2,7 +2,7 @@
 """Renders a few frames of ONE benchmark configuration and prints the kernel time from HIP events: the program the
 per-configuration rocprofv3 passes of profiles/run_profile_r02.sh run.
 
-    config_probe.py c2|c2p|c3|c4|c5 [frames]
+    config_probe.py c2|c2p|c3|c4|c5 [frames] [move]       move: the eye moves a little every frame
       c2  maze 1920x1080 recursive      c2p maze 1920x1080 packet       c4  maze 7680x4320, 4x4 samples, packet
       c3  1,000,000-triangle soup 3840x2160 packet                      c5  the same soup through the rasterizer
 """
@@ -18,6 +18,7 @@ sys.path.insert(0, ROOT)
 def main():
     cfg = sys.argv[1]
     frames = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    move = len(sys.argv) > 3 and sys.argv[3] == "move"
     import torch
     from raytracing_amd import Raytracer, scene_io
     maze = scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "maze.mrts"))
@@ -32,6 +33,8 @@ def main():
     st = torch.cuda.current_stream()
 
     def frame():
+        if move:
+            cam[12] += np.float32(1e-3)
         if mode < 0:
             rt.raster_device(cam, fb.data_ptr(), W, stream=st.cuda_stream)
         else:

@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--w", type=int, default=1920)
     ap.add_argument("--h", type=int, default=1080)
+    ap.add_argument("--spp-grid", type=int, default=1)
     args = ap.parse_args()
     from raytracing_amd import binding
     binding.LIB_PATH = os.path.join(ROOT, "raytracing_amd", "libmrt_prof.so")
@@ -38,7 +39,7 @@ def main():
     stream = torch.cuda.current_stream()
     cam = Camera()
     for mode, name in ((0, "packet"), (1, "recursive")):
-        rt.render_device(cam, fb.data_ptr(), args.w, mode=mode, stream=stream.cuda_stream)
+        rt.render_device(cam, fb.data_ptr(), args.w, mode=mode, spp_grid=args.spp_grid, stream=stream.cuda_stream)
         torch.cuda.synchronize()
         c = rt.ray_counts()
         out = np.zeros(40, np.uint64)

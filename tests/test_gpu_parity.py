@@ -492,6 +492,39 @@ def test_launches_on_two_streams_do_not_disturb_each_other(maze_scene):
     rt.close()
 
 
+def test_packet_frames_follow_the_eye_and_the_scene(maze_scene, maze_oracle):
+    """The packet path reads nodes and triangles relative to the eye from arrays the library rewrites only when the
+    eye or the scene has changed.  One context, frames on alternating streams: the same eye with another view
+    direction, another eye, the first eye again, then other scenes under an eye that stays — every frame equals the
+    oracle's."""
+    import torch
+    W, H = 256, 128
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(maze_scene)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    fb = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
+    eye_a, eye_b = (0.0, 0.0, 0.0), (2.5, 0.5, -3.0)
+    views = [("a", eye_a, (0, 0, -1)), ("a turned", eye_a, (1, 0.2, -0.3)), ("b", eye_b, (-1, 0, -1)), ("a again", eye_a, (0, 0, -1)),
+             ("b turned", eye_b, (0.3, -0.2, 1))]
+    for k, pose in enumerate(views):
+        cam = np.asarray(pose_cam(pose), np.float32)
+        rt.render_device(cam, fb.data_ptr(), W, mode=MODE_PACKET, stream=streams[k % 2].cuda_stream)
+        torch.cuda.synchronize()
+        want = maze_oracle.render(cam, W, H, mode=MODE_PACKET)
+        assert np.array_equal(fb.cpu().numpy().view(np.uint32), want["fb"]), pose[0]
+    cam = np.asarray(pose_cam(("soup", (5, 1, 4), (0, 0, -20))), np.float32)
+    for seed in (3, 4):                         # other scenes of the same size, same eye
+        soup = scene_io.soup_scene(2000, seed=seed)
+        rt.build_bvh(soup)
+        ora = oracle_lib.Oracle()
+        ora.add_scene(soup)
+        ora.build_bvh()
+        got, ids = rt.render(cam, mode=MODE_PACKET)
+        want = ora.render(cam, W, H, mode=MODE_PACKET)
+        assert np.array_equal(ids, want["ids"]) and np.array_equal(got, want["fb"])
+    rt.close()
+
+
 @pytest.mark.parametrize("W,H", [(1000, 600), (16, 8), (256, 8)])
 def test_tile_order_from_previous_frame_changes_nothing(maze_scene, W, H):
     """The persistent kernel starts the tiles that were expensive in the previous launch of the same
