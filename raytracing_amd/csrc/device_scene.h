@@ -13,6 +13,11 @@
 //             triC[k] = {p0.z, bits(triangle id)}      (raytracer.cpp:289-290)
 //           The edges come first: the first 24 bytes decide whether the triangle faces away from a
 //           ray, which dismisses about half of all tests before the rest is read.
+//   triG  : one uint4 per group of four consecutive leaf-order slots (4g .. 4g+3, whatever leaves they belong
+//           to): a box around those triangles, padded by 2^-12 of the scene's largest coordinate and rounded
+//           outwards to binary16: {lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16, 0}.  A ray that
+//           misses the box cannot hit any of the four, so the single-ray traversal skips their tests in long
+//           leaves (kernels.hip: traverse_nearest).  nullptr when the scene's coordinates do not suit binary16.
 //   attr  : 4 x float4 per triangle ID (shading only, touched once per hit):
 //             [4t]   = {normal.xyz, refl}
 //             [4t+1] = {uv0.x, uv0.y, uv1.x, uv1.y}
@@ -36,6 +41,7 @@ struct SceneDev {
     const float4* triA;
     const float4* triB;
     const float2* triC;
+    const uint4* triG;
     const float4* attr;
     const int4* tex;
     const uint8_t* texels;
@@ -83,10 +89,11 @@ struct FrameDev {
     uint32_t* tile_cost;
     const uint32_t* tile_order;
     // The scene relative to this frame's eye, for the packet traversal of the primary rays (kernels.hip:
-    // SceneGlobalEye, eye_relative_kernel); set for every packet-path launch of the one-wave-per-tile kernel.
+    // SceneGlobalEyeT, eye_relative_kernel); set for every packet-path launch of the one-wave-per-tile kernel.
     const float4* eye_nodes;
     const float4* eye_t;
     const float4* eye_q;
+    const float4* eye_g;
 };
 
 constexpr int kStatSlots = 256;
@@ -98,12 +105,13 @@ constexpr int kStatBase = kQueueBase + 16 * kTileQueues;
 constexpr int kOrderHistBase = kStatBase + 16 * kStatSlots;
 #ifdef MRT_LOOP_COUNTS
 // Diagnostic build only (make prof): per-site loop iteration counts, wave level and lane level.
-constexpr int kProfSites = 20;
+constexpr int kProfSites = 22;
 constexpr int kProfBase = kOrderHistBase + 128;
 constexpr int kCounterSlots = kProfBase + 2 * kProfSites;
 #else
 constexpr int kCounterSlots = kOrderHistBase + 128;
 #endif
+constexpr int kGroupMinLeaf = 6;       // shortest leaf whose triangles are tested group by group (triG)
 constexpr int kStackDepth = 64;        // per-ray traversal stack entries; BVH depth must stay below
 constexpr int kResidentThreads = 1024; // workgroup size of the LDS-resident kernel (16 waves)
 constexpr int kLdsBudget = 160 * 1024; // bytes of LDS per CU on gfx950

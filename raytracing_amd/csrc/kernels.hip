@@ -43,10 +43,11 @@ constexpr int kMaxReflPasses = 5, kMaxRefrPasses = 5;   // raytracer.cpp:9-10
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 
-#ifndef MRT_LEAF_CHUNK
-#define MRT_LEAF_CHUNK 16       // triangles of a leaf a lane tests before the wave looks at inner nodes again
-#endif
+#define MRT_LEAF_CHUNK 16       // triangles of a leaf a lane tests before the wave looks at inner nodes again (at most 32)
+#define MRT_GROUP_MIN kGroupMinLeaf
 
 struct Hit { int tri; float u, v; };
 
@@ -94,10 +95,17 @@ struct Watch {
 // Scene accessors: the traversals are written once and instantiated for both homes of the
 // node / triangle arrays.  Indices are in units of the array element.
 // ---------------------------------------------------------------------------------------
-struct SceneGlobal {
+// G: the kernel was launched for a scene with group boxes (triG != nullptr).  A compile-time choice: kernels for
+// scenes without them carry none of the code.
+template <bool G>
+struct SceneGlobalT {
     static constexpr bool kPrefetchLeaf = false;
     static constexpr bool kEyeRelative = false;
+    static constexpr bool kShadowGroups = true;      // the shared shadow traversal consults the group boxes
     const v4f* nodes; const v4f* triA; const v4f* triB; const v2f* triC;
+    const v4u* triG;      // group boxes (device_scene.h)
+    __device__ __forceinline__ bool has_groups() const { return G; }
+    __device__ __forceinline__ v4u group(uint32_t g) const { return triG[g]; }
     __device__ __forceinline__ v4f node(uint32_t i) const { return nodes[i]; }
     __device__ __forceinline__ v4f tri_a(uint32_t k) const { return triA[k]; }
     __device__ __forceinline__ v4f tri_b(uint32_t k) const { return triB[k]; }
@@ -116,14 +124,21 @@ struct SceneGlobal {
 // the cross product and the dot product in every wave:
 //   eyeNodes[2i], [2i+1] = {min - O, bits(firstLeft)}, {max - O, bits(count)}
 //   eyeT[k] = {tvec.xyz, dot(e2, qvec)}      eyeQ[k] = {qvec.xyz, bits(triangle id)}
-struct SceneGlobalEye : SceneGlobal {
+//   eyeG[2g], [2g+1] = {lo - O, 0}, {hi - O, 0} of group box g (device_scene.h: triG)
+template <bool G>
+struct SceneGlobalEyeT : SceneGlobalT<G> {
     static constexpr bool kEyeRelative = true;
     const v4f* eyeNodes; const v4f* eyeT; const v4f* eyeQ;
+    const v4f* eyeG;      // [2g], [2g+1] = the group box's corners minus O (nullptr: no group boxes)
 };
 struct SceneLds {
     static constexpr bool kPrefetchLeaf = true;     // request triangle k+1 before testing triangle k
     static constexpr bool kEyeRelative = false;
+    static constexpr bool kShadowGroups = true;
     MRT_LDS const v4f* nodes; MRT_LDS const v4f* triA; MRT_LDS const v4f* triB; MRT_LDS const v2f* triC;
+    MRT_LDS const v4u* triG; bool groups;
+    __device__ __forceinline__ bool has_groups() const { return groups; }
+    __device__ __forceinline__ v4u group(uint32_t g) const { return triG[g]; }
     __device__ __forceinline__ v4f node(uint32_t i) const { return nodes[i]; }
     __device__ __forceinline__ v4f tri_a(uint32_t k) const { return triA[k]; }
     __device__ __forceinline__ v4f tri_b(uint32_t k) const { return triB[k]; }
@@ -286,7 +301,7 @@ __device__ __forceinline__ void tri_test(v4f A, v4f B, v2f C, f3 O, f3 D, float&
     tri_decide<WAVE_REJECT>(det, un, vn, tn, __float_as_uint(C.y), t, h, wd);
 }
 
-// The same test for a ray that starts at the eye, from the frame's precomputed terms (SceneGlobalEye).
+// The same test for a ray that starts at the eye, from the frame's precomputed terms (SceneGlobalEyeT).
 __device__ __forceinline__ void tri_test_eye(v4f A, v2f Blo, v4f T, v4f Q, f3 D, float& t, Hit& h, Watch& wd) {
     const f3 e1 = {A.x, A.y, A.z}, e2 = {A.w, Blo.x, Blo.y};
     const f3 pvec = cross(D, e2);
@@ -323,6 +338,59 @@ struct LaneStack3 {
     }
 };
 
+// Can the ray O + s / r (r = 1/D, every component finite and non-zero) with 0 <= s <= t touch the group box G
+// (device_scene.h: triG)?  Approximate arithmetic: the box's padding is four thousand times its rounding errors.
+// Skipping a group is exact for every ray whose triangle tests are well conditioned: the test then places the hit
+// within a ten-thousandth of the triangle's size, far inside the box's padding.  The exception is a ray that runs
+// IN the plane of a triangle it passes beside (within about 1e-5 rad: harness in tests/native/check_groups.cpp): all
+// numerators of its test are rounding noise, the reference's verdict for it is noise too, and a box cannot
+// reproduce noise.  Rays that start on a surface meet that case with the surface's own coplanar neighbours, so a
+// secondary or shadow ray within a thousandth of its surface's plane skips nothing.
+__device__ __forceinline__ bool not_grazing(f3 D, f3 surface_normal) { return fabsf(dot(D, surface_normal)) >= 1e-3f; }
+
+__device__ __forceinline__ void group_corners(v4u G, f3& lo, f3& hi) {
+    const uint32_t w0 = G.x, w1 = G.y, w2 = G.z;      // (a bit cast taken straight from a vector element reads element 0)
+    const v2h a = __builtin_bit_cast(v2h, w0), b = __builtin_bit_cast(v2h, w1), c = __builtin_bit_cast(v2h, w2);
+    lo = {(float)a.x, (float)a.y, (float)b.x};
+    hi = {(float)b.y, (float)c.x, (float)c.y};
+}
+// lo, hi: the box's corners relative to the ray's origin
+__device__ __forceinline__ bool group_touched_rel(f3 lo, f3 hi, f3 r, float t) {
+    const f3 t0 = lo * r, t1 = hi * r;
+    const float tn = hw_max3(hw_min(t0.x, t1.x), hw_min(t0.y, t1.y), hw_min(t0.z, t1.z));
+    const float tf = hw_min3(hw_max(t0.x, t1.x), hw_max(t0.y, t1.y), hw_max(t0.z, t1.z));
+    return tn <= tf && tf >= 0.0f && tn <= t;
+}
+__device__ __forceinline__ bool group_touched(v4u G, f3 O, f3 r, float t) {
+    f3 lo, hi;
+    group_corners(G, lo, hi);
+    return group_touched_rel(lo - O, hi - O, r, t);
+}
+
+// A leaf that all calling lanes walk together (packet leaves, the shared shadow traversal), group by group: the
+// four triangles of a group are skipped when no calling lane's ray touches the group's box.  tri(k) tests triangle k
+// and returns true when the walk can stop.  r_ok: this lane's reciprocal direction is an ordinary number on every
+// axis (a lane without that never lets a group be skipped).  first, count: wave-uniform.
+template <bool EYE, class SC, class TRI>
+__device__ __forceinline__ void walk_leaf_by_groups(const SC& sc, uint32_t first, uint32_t count, f3 O, f3 r, bool r_ok, const float& t, Watch& wd, TRI&& tri) {
+    const uint32_t end = first + count;
+    for (uint32_t k = first; k < end;) {
+        const uint32_t gend = ((k | 3u) + 1u) < end ? ((k | 3u) + 1u) : end;
+        if (gend - k >= 2u) {
+            MRT_TICK(wd, 21);
+            bool touched;
+            if constexpr (EYE) {
+                const v4f glo = sc.eyeG[2 * (k >> 2)], ghi = sc.eyeG[2 * (k >> 2) + 1];
+                touched = group_touched_rel(xyz(glo), xyz(ghi), r, t);
+            } else {
+                touched = group_touched(sc.group(k >> 2), O, r, t);
+            }
+            if (!__any(!r_ok || touched)) { k = gend; continue; }
+        }
+        for (; k < gend; ++k) if (tri(k)) return;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // 64-ray packet traversal: BVH::TraverseRayPacket, BVHNode::TraversePacket and
 // IntersectPrimitivesPacket (raytracer.cpp:1349-1464).  Must be called by all 64 lanes.
@@ -351,6 +419,10 @@ __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f
             else slab_terms((bmin - O) * rD, (bmax - O) * rD, tn, tf);
         }
     };
+    // the group boxes of long leaves are tested with the reciprocal of D itself (a caller of the packet operator may
+    // hand over any rD)
+    const f3 rg = 1.0f / D;
+    const bool rg_ok = fabsf(rg.x) < INFINITY && fabsf(rg.y) < INFINITY && fabsf(rg.z) < INFINITY;
     LaneStack1 work;
     work.push(lane, 0u);                       // scan(root, f = 0): raytracer.cpp:1351-1357
     while (work.sp > 0) {
@@ -370,7 +442,14 @@ __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f
         for (;;) {                             // visit(node = {first,count}, firstActive = i)
             if (count != 0) {
                 if (lane >= i) {
-                    if constexpr (SC::kEyeRelative) {
+                    if (sc.has_groups() && count >= (uint32_t)MRT_GROUP_MIN) {
+                        walk_leaf_by_groups<SC::kEyeRelative>(sc, first, count, O, rg, rg_ok, t, wd, [&](uint32_t k) {
+                            MRT_TICK(wd, 10);
+                            if constexpr (SC::kEyeRelative) tri_test_eye(sc.tri_a(k), sc.tri_b_lo(k), sc.eyeT[k], sc.eyeQ[k], D, t, h, wd);
+                            else tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
+                            return false;
+                        });
+                    } else if constexpr (SC::kEyeRelative) {
                         for (uint32_t k = first; k < first + count; ++k) {
                             MRT_TICK(wd, 10);
                             tri_test_eye(sc.tri_a(k), sc.tri_b_lo(k), sc.eyeT[k], sc.eyeQ[k], D, t, h, wd);
@@ -429,11 +508,12 @@ __device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, 
 // ---------------------------------------------------------------------------------------
 // Single-ray nearest-hit traversal: BVH::Traverse + BVHNode::Traverse + IntersectPrimitives
 // (raytracer.cpp:945-950, 1204-1264, 1328-1346).  Returns true when a hit was recorded.
+// skip_ok: this ray may skip groups of a long leaf whose box it misses (see not_grazing).
 // `stack` points at this lane's column of an LDS array laid out [entry][64 lanes].  Lanes
 // first walk inner nodes until each holds a leaf, then all leaves are processed together.
 // ---------------------------------------------------------------------------------------
 template <class SC, typename STP>
-__device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool coords_ok, f3 O, f3 D, float& t, Hit& h, STP stack, Watch& wd) {
+__device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool coords_ok, f3 O, f3 D, bool skip_ok, float& t, Hit& h, STP stack, Watch& wd) {
     h.tri = -1;
     if (n_tris == 0) return false;
     const v4f root0 = sc.node(0), root1 = sc.node(1);
@@ -445,6 +525,8 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
     MRT_TICK(wd, 2);
     const RayDiv R = make_ray_div(O, D, coords_ok);
     const bool shortcut = __all(R.shortcut);
+    // groups of a long leaf may be skipped for rays whose reciprocal direction is an ordinary number on every axis
+    const bool may_skip = sc.has_groups() && skip_ok && fabsf(R.r.x) < INFINITY && fabsf(R.r.y) < INFINITY && fabsf(R.r.z) < INFINITY;
     int sp = 0;
     uint32_t first = wbits(root0), count = wbits(root1);
     bool alive = true;
@@ -481,8 +563,27 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
             // in between instead of waiting for the longest leaf of the wave.  Per lane the sequence of tests
             // is unchanged.
             const uint32_t n_now = count < (uint32_t)MRT_LEAF_CHUNK ? count : (uint32_t)MRT_LEAF_CHUNK;
-            for (uint32_t k = first; k < first + n_now; ++k) {
+            // A ray that misses the padded box around four consecutive triangles cannot pass the test of any of
+            // them (the test computes a point of the triangle to within rounding; only for a ray that lies IN a
+            // triangle's plane is every numerator of the test rounding noise, and such a ray's outcome is noise in
+            // the reference too).  todo: bit j = triangle first + j is still to be tested; the order of the tests
+            // that remain is the leaf's.
+            uint32_t todo = n_now >= 32u ? ~0u : (1u << n_now) - 1u;
+            const bool long_leaf = may_skip && n_now >= (uint32_t)MRT_GROUP_MIN;
+            if (__any(long_leaf)) {
+                const uint32_t shift = first & 3u, g0 = first >> 2;
+                const uint32_t n_groups = long_leaf ? (shift + n_now + 3u) >> 2 : 0u;     // at most MRT_LEAF_CHUNK / 4 + 1
+                unsigned long long keep = 0;
+                for (uint32_t i = 0; i < n_groups; ++i) {
+                    MRT_TICK(wd, 20);
+                    if (group_touched(sc.group(g0 + i), O, R.r, t)) keep |= 0xfull << (4u * i);
+                }
+                if (long_leaf) todo &= (uint32_t)(keep >> shift);
+            }
+            while (todo) {
                 MRT_TICK(wd, 1);
+                const uint32_t k = first + (uint32_t)__builtin_ctz(todo);
+                todo &= todo - 1u;
                 tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
             }
             first += n_now; count -= n_now;
@@ -510,7 +611,7 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
 // Must be called by all 64 lanes; `take_part` selects the lanes that really have a ray.
 // ---------------------------------------------------------------------------------------
 template <class SC>
-__device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coords_ok, f3 O, f3 D, bool take_part, int lane, Watch& wd) {
+__device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coords_ok, f3 O, f3 D, bool take_part, bool skip_ok, int lane, Watch& wd) {
     if (n_tris == 0) return false;
     const v4f root0 = sc.node(0), root1 = sc.node(1);
     float tn;
@@ -519,6 +620,7 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
     if (m == 0) return false;
     const RayDiv R = make_ray_div(O, D, coords_ok);
     const bool shortcut = !__any(take_part && !R.shortcut);
+    const bool r_ok = skip_ok && fabsf(R.r.x) < INFINITY && fabsf(R.r.y) < INFINITY && fabsf(R.r.z) < INFINITY;
     float t = INFINITY;
     Hit h;
     h.tri = -1;
@@ -535,7 +637,13 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
         const uint32_t first = sc.node_first(node), count = sc.node_count(node);
         if (count != 0) {
             if ((m >> lane) & 1ull) {
-                if constexpr (SC::kPrefetchLeaf) {
+                if (SC::kShadowGroups && sc.has_groups() && count >= (uint32_t)MRT_GROUP_MIN) {
+                    walk_leaf_by_groups<false>(sc, first, count, O, R.r, r_ok, t, wd, [&](uint32_t k) {
+                        MRT_TICK(wd, 5);
+                        if (h.tri < 0) tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
+                        return !__any(h.tri < 0);
+                    });
+                } else if constexpr (SC::kPrefetchLeaf) {
                     v4f A = sc.tri_a(first), B = sc.tri_b(first);
                     v2f C = sc.tri_c(first);
                     const uint32_t last = first + count - 1;
@@ -702,7 +810,7 @@ __device__ __forceinline__ void direct_light(const SC& sc, const SceneDev& S, bo
     for (int i = 0; i < S.n_lights; ++i) {
         const float4 lp = S.lights[2 * i], lc = S.lights[2 * i + 1];
         const f3 L = lit ? normalize(xyz(lp) - hit) : f3{0.0f, 0.0f, 1.0f};
-        bool occluded = occluded_wave(sc, S.n_tris, S.coords_ok != 0, hit, L, lit, lane, wd);
+        bool occluded = occluded_wave(sc, S.n_tris, S.coords_ok != 0, hit, L, lit, not_grazing(L, s.normal), lane, wd);
         if constexpr (OBJ) { if (lit && !occluded) occluded = objects_occlude(S, hit, L); }
         if (lit) {
             ++n_shadow;
@@ -749,6 +857,7 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
     float curIndex = 1.0f, tmax = 100000000;
     f4 ret = MRT_BACKGROUND;
     bool tracing = true, first = true;
+    bool skip_ok = true;        // the current ray may skip groups of long leaves (not_grazing)
     ShadeState F;
     while (__any(tracing)) {
         if (wd.expired(32)) break;
@@ -758,7 +867,7 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
         float t = tmax;
         bool isHit = false;
         MRT_PHASE_BEGIN(wd);
-        if (tracing) isHit = traverse_nearest(sc, S.n_tris, S.coords_ok != 0, O, D, t, h, stack, wd);
+        if (tracing) isHit = traverse_nearest(sc, S.n_tris, S.coords_ok != 0, O, D, skip_ok, t, h, stack, wd);
         if constexpr (OBJ) { if (tracing) { trace_objects(S, O, D, t, h); isHit = h.tri != -1; } }
         MRT_PHASE_END(wd, 16);
         if (tracing && first) { primary = h; first = false; }
@@ -799,6 +908,7 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
                         fr[17] = F.t; fr[18] = F.refl; fr[19] = F.refr; fr[20] = F.rindex; fr[21] = F.curIndex;
                         fr[23] = 1.0f;
                         O = F.hit; D = reflect(F.D, F.normal); tmax = INFINITY; curIndex = F.curIndex;
+                        skip_ok = not_grazing(D, F.normal);
                         tracing = true;
                         break;
                     }
@@ -820,6 +930,7 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
                             fr[4] = expf(absorbance.x); fr[5] = expf(absorbance.y); fr[6] = expf(absorbance.z);
                             fr[23] = 2.0f;
                             O = F.hit + T * kEpsilon; D = T; tmax = INFINITY; curIndex = rindex;
+                            skip_ok = not_grazing(D, F.normal);
                             tracing = true;
                             break;
                         }
@@ -990,13 +1101,15 @@ __device__ __forceinline__ int traverse_depth(const SC& sc, int n_tris, f3 O, f3
     return depth;
 }
 
-__device__ __forceinline__ SceneGlobal global_scene(const SceneDev& S) {
-    return SceneGlobal{reinterpret_cast<const v4f*>(S.nodes), reinterpret_cast<const v4f*>(S.triA),
-                       reinterpret_cast<const v4f*>(S.triB), reinterpret_cast<const v2f*>(S.triC)};
+template <bool G>
+__device__ __forceinline__ SceneGlobalT<G> global_scene(const SceneDev& S) {
+    return SceneGlobalT<G>{reinterpret_cast<const v4f*>(S.nodes), reinterpret_cast<const v4f*>(S.triA),
+                       reinterpret_cast<const v4f*>(S.triB), reinterpret_cast<const v2f*>(S.triC),
+                       reinterpret_cast<const v4u*>(S.triG)};
 }
 
 // Scene in global memory: one 64-thread workgroup (one wave) per tile.  SD = stack entries.
-template <int MODE, int SD, bool OBJ = false>
+template <int MODE, int SD, bool OBJ, bool G>
 #ifndef MRT_PACKET_WAVES
 #define MRT_PACKET_WAVES 8      // waves per SIMD the packet kernel is compiled for (register budget 512 / n)
 #endif
@@ -1014,17 +1127,18 @@ __global__ __launch_bounds__(64, MODE == 0 ? MRT_PACKET_WAVES : MRT_RECURSIVE_WA
     const int tile = ((q / kXcdRun) * kXcds + b % kXcds) * kXcdRun + q % kXcdRun;
     if (tile >= F.n_tiles) return;
     if constexpr (MODE == 0) {
-        const SceneGlobalEye sc{global_scene(S), reinterpret_cast<const v4f*>(F.eye_nodes), reinterpret_cast<const v4f*>(F.eye_t),
-                                reinterpret_cast<const v4f*>(F.eye_q)};
+        const SceneGlobalEyeT<G> sc{global_scene<G>(S), reinterpret_cast<const v4f*>(F.eye_nodes), reinterpret_cast<const v4f*>(F.eye_t),
+                                reinterpret_cast<const v4f*>(F.eye_q), reinterpret_cast<const v4f*>(F.eye_g)};
         render_tile<MODE, OBJ>(sc, S, F, tile, lane, (MRT_LDS uint32_t*)lds_stack + lane);
     } else {
-        render_tile<MODE, OBJ>(global_scene(S), S, F, tile, lane, (MRT_LDS uint32_t*)lds_stack + lane);
+        render_tile<MODE, OBJ>(global_scene<G>(S), S, F, tile, lane, (MRT_LDS uint32_t*)lds_stack + lane);
     }
 }
 
-// The frame's eye-relative copy of the nodes and triangles (SceneGlobalEye): one thread per node record and
+// The frame's eye-relative copy of the nodes and triangles (SceneGlobalEyeT): one thread per node record and
 // per triangle, the operations of the box and triangle tests in their order.
-__global__ __launch_bounds__(256) void eye_relative_kernel(SceneDev S, float ox, float oy, float oz, float4* eye_nodes, float4* eye_t, float4* eye_q) {
+__global__ __launch_bounds__(256) void eye_relative_kernel(SceneDev S, float ox, float oy, float oz, float4* eye_nodes, float4* eye_t, float4* eye_q,
+                                                           float4* eye_g) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const f3 O = {ox, oy, oz};
     if (i < 2u * (uint32_t)S.n_node_slots) {
@@ -1041,6 +1155,14 @@ __global__ __launch_bounds__(256) void eye_relative_kernel(SceneDev S, float ox,
         const float tn = dot(e2, qvec);
         eye_t[i] = make_float4(tvec.x, tvec.y, tvec.z, tn);
         eye_q[i] = make_float4(qvec.x, qvec.y, qvec.z, C.y);
+    }
+    if (S.triG && i < ((uint32_t)S.n_tris + 3u) / 4u) {
+        const uint4 g = S.triG[i];
+        f3 lo, hi;
+        group_corners(v4u{g.x, g.y, g.z, g.w}, lo, hi);
+        lo = lo - O; hi = hi - O;      // rounding: a ten-millionth of the operands, the padding is 2^-12 of the scene
+        eye_g[2 * i] = make_float4(lo.x, lo.y, lo.z, 0.0f);
+        eye_g[2 * i + 1] = make_float4(hi.x, hi.y, hi.z, 0.0f);
     }
 }
 
@@ -1065,7 +1187,7 @@ __global__ __launch_bounds__(64) void depth_tiles_kernel(SceneDev S, FrameDev F)
     float t = 100000000;
     Hit h;
     h.u = 0; h.v = 0;
-    const int depth = traverse_depth(global_scene(S), S.n_tris, O, D, t, h, (MRT_LDS uint32_t*)lds_stack + lane, wd);
+    const int depth = traverse_depth(global_scene<false>(S), S.n_tris, O, D, t, h, (MRT_LDS uint32_t*)lds_stack + lane, wd);
     F.fb[(size_t)y * F.pitch + x] = (uint32_t)depth;
     if (F.hit_ids) F.hit_ids[(size_t)y * F.width + x] = h.tri;
     int m = depth;
@@ -1113,7 +1235,9 @@ __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_t
     MRT_LDS v4f* l_a = l_nodes + n_node_v4;
     MRT_LDS v4f* l_b = l_a + n_tri;
     MRT_LDS v2f* l_c = (MRT_LDS v2f*)(l_b + n_tri);
-    MRT_LDS uint16_t* l_stacks = (MRT_LDS uint16_t*)(l_c + n_tri + (n_tri & 1u));
+    MRT_LDS v4u* l_g = (MRT_LDS v4u*)(l_c + n_tri + (n_tri & 1u));
+    const uint32_t n_groups = (n_tri + 3u) / 4u;
+    MRT_LDS uint16_t* l_stacks = (MRT_LDS uint16_t*)(l_g + n_groups);
     {
         const v4f* gn = reinterpret_cast<const v4f*>(S.nodes);
         const v4f* ga = reinterpret_cast<const v4f*>(S.triA);
@@ -1121,9 +1245,13 @@ __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_t
         const v2f* gc = reinterpret_cast<const v2f*>(S.triC);
         for (uint32_t i = threadIdx.x; i < n_node_v4; i += blockDim.x) l_nodes[i] = gn[i];
         for (uint32_t i = threadIdx.x; i < n_tri; i += blockDim.x) { l_a[i] = ga[i]; l_b[i] = gb[i]; l_c[i] = gc[i]; }
+        if (S.triG) {
+            const v4u* gg = reinterpret_cast<const v4u*>(S.triG);
+            for (uint32_t i = threadIdx.x; i < n_groups; i += blockDim.x) l_g[i] = gg[i];
+        }
     }
     __syncthreads();
-    const SceneLds sc{l_nodes, l_a, l_b, l_c};
+    const SceneLds sc{l_nodes, l_a, l_b, l_c, l_g, S.triG != nullptr};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #ifdef MRT_LOOP_COUNTS
     const unsigned long long t_ready = __builtin_readcyclecounter();
@@ -1242,7 +1370,7 @@ __global__ __launch_bounds__(64) void trace_packets_kernel(SceneDev S, int n_pac
     Hit h;
     h.tri = -1; h.u = 0; h.v = 0;
     Watch wd{watch_budget(S.n_node_slots, S.n_tris), flag};
-    traverse_packet(global_scene(S), S.n_tris, o, d, rd, tt, h, lane, wd);
+    traverse_packet(global_scene<false>(S), S.n_tris, o, d, rd, tt, h, lane, wd);
     t[r] = tt; tri[r] = h.tri; u[r] = h.u; v[r] = h.v;
 }
 
@@ -1259,7 +1387,7 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(SceneDev S, int n_rays, 
     Hit h;
     h.u = 0; h.v = 0;
     Watch wd{watch_budget(S.n_node_slots, S.n_tris), flag};
-    traverse_nearest(global_scene(S), S.n_tris, S.coords_ok != 0, o, d, tt, h, (MRT_LDS uint32_t*)lds_stack + lane, wd);
+    traverse_nearest(global_scene<false>(S), S.n_tris, S.coords_ok != 0, o, d, true, tt, h, (MRT_LDS uint32_t*)lds_stack + lane, wd);
     t[r] = tt; tri[r] = h.tri; u[r] = h.u; v[r] = h.v;
 }
 
@@ -1267,7 +1395,7 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(SceneDev S, int n_rays, 
 // Host-callable launchers (used by the C ABI in mrt_api.cpp)
 // ---------------------------------------------------------------------------------------
 size_t resident_scene_bytes(int n_node_slots, int n_tris) {
-    return (size_t)n_node_slots * 32 + (size_t)n_tris * 40 + ((n_tris & 1) ? 8 : 0);
+    return (size_t)n_node_slots * 32 + (size_t)n_tris * 40 + ((n_tris & 1) ? 8 : 0) + (size_t)((n_tris + 3) / 4) * 16;
 }
 size_t resident_lds_bytes(int n_node_slots, int n_tris, int stack_entries) {
     return resident_scene_bytes(n_node_slots, n_tris) + (size_t)(kResidentThreads / 64) * stack_entries * 64 * sizeof(uint16_t);
@@ -1277,10 +1405,12 @@ template <int MODE>
 static hipError_t launch_global_mode(const SceneDev& S, const FrameDev& F, hipStream_t stream) {
     const int group = kXcds * kXcdRun;
     const dim3 grid((unsigned)((F.n_tiles + group - 1) / group * group)), block(64);
-    if (S.n_objects > 0) hipLaunchKernelGGL((render_tiles_global<MODE, kStackDepth, true>), grid, block, 0, stream, S, F);
-    else if (F.stack_entries <= 16) hipLaunchKernelGGL((render_tiles_global<MODE, 16>), grid, block, 0, stream, S, F);
-    else if (F.stack_entries <= 32) hipLaunchKernelGGL((render_tiles_global<MODE, 32>), grid, block, 0, stream, S, F);
-    else hipLaunchKernelGGL((render_tiles_global<MODE, kStackDepth>), grid, block, 0, stream, S, F);
+    const bool g = S.triG != nullptr;
+    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, 0, stream, S, F); };
+    if (S.n_objects > 0) g ? go(render_tiles_global<MODE, kStackDepth, true, true>) : go(render_tiles_global<MODE, kStackDepth, true, false>);
+    else if (F.stack_entries <= 16) g ? go(render_tiles_global<MODE, 16, false, true>) : go(render_tiles_global<MODE, 16, false, false>);
+    else if (F.stack_entries <= 32) g ? go(render_tiles_global<MODE, 32, false, true>) : go(render_tiles_global<MODE, 32, false, false>);
+    else g ? go(render_tiles_global<MODE, kStackDepth, false, true>) : go(render_tiles_global<MODE, kStackDepth, false, false>);
     return hipGetLastError();
 }
 
@@ -1312,10 +1442,10 @@ hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool re
     return mode == 0 ? launch_global_mode<0>(S, F, stream) : launch_global_mode<1>(S, F, stream);
 }
 
-hipError_t launch_eye_relative(const SceneDev& S, const float eye[3], float4* eye_nodes, float4* eye_t, float4* eye_q, hipStream_t stream) {
+hipError_t launch_eye_relative(const SceneDev& S, const float eye[3], float4* eye_nodes, float4* eye_t, float4* eye_q, float4* eye_g, hipStream_t stream) {
     const uint32_t n = std::max(2u * (uint32_t)S.n_node_slots, (uint32_t)S.n_tris);
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(eye_relative_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, S, eye[0], eye[1], eye[2], eye_nodes, eye_t, eye_q);
+    hipLaunchKernelGGL(eye_relative_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, S, eye[0], eye[1], eye[2], eye_nodes, eye_t, eye_q, eye_g);
     return hipGetLastError();
 }
 

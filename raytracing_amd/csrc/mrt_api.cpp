@@ -21,7 +21,7 @@
 
 namespace mrt {
 hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool resident, int n_cus, int resident_threads, hipStream_t stream);
-hipError_t launch_eye_relative(const SceneDev& S, const float eye[3], float4* eye_nodes, float4* eye_t, float4* eye_q, hipStream_t stream);
+hipError_t launch_eye_relative(const SceneDev& S, const float eye[3], float4* eye_nodes, float4* eye_t, float4* eye_q, float4* eye_g, hipStream_t stream);
 hipError_t prepare_render_kernels();
 hipError_t launch_depth_view(const SceneDev& S, const FrameDev& F, hipStream_t stream);
 hipError_t launch_order_tiles(const uint32_t* cost, uint32_t* packed, uint32_t* hist, uint32_t* order, int n, hipStream_t stream);
@@ -113,9 +113,11 @@ struct mrt_ctx {
     HostBVH bvh;
     DevBuf<float4> d_nodes, d_triA, d_triB, d_attr, d_lights;
     DevBuf<float2> d_triC;
-    // nodes and triangles relative to the eye of the last packet-path frame (kernels.hip: SceneGlobalEye), sized at
+    DevBuf<uint4> d_triG;
+    bool has_groups = false;
+    // nodes and triangles relative to the eye of the last packet-path frame (kernels.hip: SceneGlobalEyeT), sized at
     // scene upload; eye_key = the eye position and scene_serial they were made for
-    DevBuf<float4> d_eye_nodes, d_eye_t, d_eye_q;
+    DevBuf<float4> d_eye_nodes, d_eye_t, d_eye_q, d_eye_g;
     uint32_t eye_key[4] = {0, 0, 0, 0};
     bool resident = false;      // scene small enough for the LDS-resident kernel
     unsigned scene_serial = 0;  // counts scene uploads
@@ -178,6 +180,7 @@ int fail(mrt_ctx* c, int code, const std::string& msg) {
 void refresh_scene_view(mrt_ctx* c) {
     SceneDev& S = c->scene;
     S.nodes = c->d_nodes.p; S.triA = c->d_triA.p; S.triB = c->d_triB.p; S.triC = c->d_triC.p; S.attr = c->d_attr.p;
+    S.triG = c->has_groups ? c->d_triG.p : nullptr;
     S.tex = c->d_tex.p; S.texels = c->d_texels.p; S.pal = c->d_pal.p;
     S.lights = c->d_lights.p;
     S.objects = c->objects.empty() ? nullptr : c->d_objects.p;
@@ -321,10 +324,10 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
         memcpy(key, F.cam, 12);
         key[3] = c->scene_serial;
         if (memcmp(key, c->eye_key, sizeof key) != 0) {
-            MRT_HIP(c, launch_eye_relative(c->scene, F.cam, c->d_eye_nodes.p, c->d_eye_t.p, c->d_eye_q.p, stream));
+            MRT_HIP(c, launch_eye_relative(c->scene, F.cam, c->d_eye_nodes.p, c->d_eye_t.p, c->d_eye_q.p, c->d_eye_g.p, stream));
             memcpy(c->eye_key, key, sizeof key);
         }
-        F.eye_nodes = c->d_eye_nodes.p; F.eye_t = c->d_eye_t.p; F.eye_q = c->d_eye_q.p;
+        F.eye_nodes = c->d_eye_nodes.p; F.eye_t = c->d_eye_t.p; F.eye_q = c->d_eye_q.p; F.eye_g = c->d_eye_g.p;
     }
     MRT_HIP(c, launch_render(c->scene, F, mode, resident, c->n_cus, env_int("MRT_RESIDENT_THREADS", kResidentThreads), stream));
     MRT_HIP(c, hipEventRecord(c->last_done, stream));
@@ -580,6 +583,73 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
             attr[4 * id + 3] = make_float4(bits2f((uint32_t)t.tex), 0, 0, 0);
         }
     });
+    // boxes around groups of four consecutive leaf-order slots (device_scene.h: triG)
+    float largest = 0.0f;
+    for (int a = 0; a < 3 && B.n_tris > 0; ++a) {
+        const float lo = a == 0 ? B.nmin[0].x : a == 1 ? B.nmin[0].y : B.nmin[0].z, hi = a == 0 ? B.nmax[0].x : a == 1 ? B.nmax[0].y : B.nmax[0].z;
+        largest = std::max(largest, std::max(fabsf(lo), fabsf(hi)));
+    }
+    // binary16 keeps 11 bits between 2^-14 and 65504: scenes far from that range go without groups
+    c->has_groups = B.n_tris > 0 && largest >= 0x1p-6f && largest <= 0x1p14f;
+    if (c->has_groups) {
+        // Worth it?  Only leaves of kGroupMinLeaf triangles or more consult the boxes, and a box helps when it is
+        // small beside its leaf's: compare surface areas (the chance that a ray through the leaf also meets the
+        // group), weighted by triangles.  A soup of unrelated triangles has short leaves or groups as large as
+        // the leaf, and goes without.
+        auto area = [](f3 lo, f3 hi) {
+            const double dx = std::max(0.0f, hi.x - lo.x), dy = std::max(0.0f, hi.y - lo.y), dz = std::max(0.0f, hi.z - lo.z);
+            return dx * dy + dy * dz + dz * dx;
+        };
+        double long_tris = 0, weighted = 0;
+        for (size_t i = 0; i <= B.pool_ptr; ++i) {
+            if (i == 1 || i == 2 || B.count[i] < (uint32_t)kGroupMinLeaf) continue;
+            const double leaf_area = area(B.nmin[i], B.nmax[i]);
+            const size_t first = B.first[i], end = first + B.count[i];
+            for (size_t k = first; k < end;) {
+                const size_t gend = std::min(end, (k | 3) + 1);
+                f3 lo = {INFINITY, INFINITY, INFINITY}, hi = {-INFINITY, -INFINITY, -INFINITY};
+                for (size_t j = k; j < gend; ++j) {
+                    const HostTri& t = B.tris[B.idx[j]];
+                    for (const f3& p : {t.p0, t.p1, t.p2}) {
+                        lo = {std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z)};
+                        hi = {std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z)};
+                    }
+                }
+                weighted += (double)(gend - k) * (leaf_area > 0 ? std::min(1.0, area(lo, hi) / leaf_area) : 1.0);
+                long_tris += (double)(gend - k);
+                k = gend;
+            }
+        }
+        c->has_groups = long_tris >= 0.05 * (double)B.n_tris && weighted <= 0.6 * long_tris;
+        if (timing) fprintf(stderr, "mrt_scene_upload: group boxes %s: %.0f of %u triangles in long leaves, mean box-to-leaf area %.2f\n",
+                            c->has_groups ? "on" : "off", long_tris, B.n_tris, long_tris > 0 ? weighted / long_tris : 0.0);
+    }
+    const size_t n_groups = ((size_t)B.n_tris + 3) / 4;
+    std::vector<uint4> triG(c->has_groups ? n_groups : 0);
+    if (c->has_groups) {
+        const float pad = largest * 0x1p-12f;
+        parallel_for(n_groups, [&](size_t b, size_t e) {
+            for (size_t g = b; g < e; ++g) {
+                f3 lo = {INFINITY, INFINITY, INFINITY}, hi = {-INFINITY, -INFINITY, -INFINITY};
+                bool sliver = false;
+                for (size_t k = 4 * g; k < std::min<size_t>(4 * g + 4, B.n_tris); ++k) {
+                    const HostTri& t = B.tris[B.idx[k]];
+                    sliver = sliver || triangle_is_sliver(t.p0, t.p1, t.p2);
+                    for (const f3& p : {t.p0, t.p1, t.p2}) {
+                        lo = {std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z)};
+                        hi = {std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z)};
+                    }
+                }
+                if (sliver) {           // a box no ray misses
+                    triG[g] = make_uint4(0xfc00fc00u, 0x7c00fc00u, 0x7c007c00u, 0u);
+                    continue;
+                }
+                const uint32_t h[6] = {half_outward(lo.x - pad, false), half_outward(lo.y - pad, false), half_outward(lo.z - pad, false),
+                                       half_outward(hi.x + pad, true), half_outward(hi.y + pad, true), half_outward(hi.z + pad, true)};
+                triG[g] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), 0u);
+            }
+        });
+    }
     std::vector<int4> tex(refit ? 0 : n_textures);
     std::vector<uint8_t> texels;
     std::vector<uint32_t> pal(refit ? 0 : (size_t)n_textures * 32 * 256);
@@ -595,6 +665,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     MRT_HIP(c, c->d_triA.upload(triA, c->stream));
     MRT_HIP(c, c->d_triB.upload(triB, c->stream));
     MRT_HIP(c, c->d_triC.upload(triC, c->stream));
+    if (c->has_groups) MRT_HIP(c, c->d_triG.upload(triG, c->stream));
     MRT_HIP(c, c->d_attr.upload(attr, c->stream));
     if (!refit) {
         MRT_HIP(c, c->d_tex.upload(tex, c->stream));
@@ -605,6 +676,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     MRT_HIP(c, c->d_eye_nodes.ensure(std::max<size_t>(1, 2 * slots)));
     MRT_HIP(c, c->d_eye_t.ensure(std::max<size_t>(1, B.n_tris)));
     MRT_HIP(c, c->d_eye_q.ensure(std::max<size_t>(1, B.n_tris)));
+    MRT_HIP(c, c->d_eye_g.ensure(std::max<size_t>(2, 2 * n_groups)));
     stage("upload ray-path arrays");
     if (int rc = raster_upload(c->raster, meshes, n_meshes, c->stream, err)) return fail(c, rc, err);
     MRT_HIP(c, hipStreamSynchronize(c->stream));

@@ -103,6 +103,48 @@ MRT_HD int watch_budget(int n_node_slots, int n_tris) {
     return b > 0x7fffffffll ? 0x7fffffff : (int)b;
 }
 
+// ---- binary16 bounds that never shrink a box -------------------------------------------------
+// half_outward(x, up): the binary16 value nearest to x on the side asked for -- not below x (up) or not
+// above x (!up) -- restricted to zero, the normal numbers and the infinities, so that the result reads back
+// the same whether or not the reader flushes subnormal halves.  Finite x only.
+MRT_HD uint16_t half_outward(float x, bool up) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint32_t sign = u >> 31, mag = u & 0x7fffffffu;
+    const bool away = (up && !sign) || (!up && sign);          // round the magnitude up?
+    const int e = (int)(mag >> 23) - 127 + 15;                 // biased binary16 exponent
+    uint32_t h;
+    if (mag == 0) h = 0;
+    else if (e >= 31) h = away ? 0x7c00u : 0x7bffu;            // beyond the largest half: infinity or 65504
+    else if (e <= 0) h = away ? 0x0400u : 0u;                  // below the smallest normal half: 2^-14 or zero
+    else {
+        h = ((uint32_t)e << 10) | ((mag >> 13) & 0x3ffu);
+        if (away && (mag & 0x1fffu)) ++h;                      // a carry runs into the exponent, up to infinity
+    }
+    return (uint16_t)((sign << 15) | h);
+}
+// the value of a binary16 bit pattern (zero, normal or infinite: what half_outward produces)
+MRT_HD float half_value(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 31u, m = h & 0x3ffu;
+    uint32_t u;
+    if (e == 0) u = sign;
+    else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+    else u = sign | ((e - 15 + 127) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// A triangle whose edges e1, e2 enclose less than a thousandth of a radian (or that has an edge of length zero):
+// the determinant of its ray test is small against its rounding errors for EVERY ray, so nothing can be said
+// about where such a test reports hits.  Groups holding one are never skipped.
+MRT_HD bool triangle_is_sliver(f3 p0, f3 p1, f3 p2) {
+    const f3 e1 = p1 - p0, e2 = p2 - p0, n = cross(e1, e2);
+    const double nn = (double)n.x * n.x + (double)n.y * n.y + (double)n.z * n.z;
+    const double a = (double)e1.x * e1.x + (double)e1.y * e1.y + (double)e1.z * e1.z, b = (double)e2.x * e2.x + (double)e2.y * e2.y + (double)e2.z * e2.z;
+    return !(nn > 1e-6 * a * b);
+}
+
 MRT_HD uint32_t f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 MRT_HD float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 

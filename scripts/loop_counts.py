@@ -17,6 +17,7 @@ SITES = {0: "nearest: inner-node step", 1: "nearest: leaf triangle", 2: "nearest
          6: "shared tri past back-face", 7: "shared tri exact tail",
          8: "packet: work item", 9: "packet: inner visit", 10: "packet: leaf triangle", 11: "shader round",
          15: "shadow: inner node exact fallback", 14: "longest wave life | latest scene-copy end", 18: "sum: scene copy clocks | clocks in tiles", 19: "sum: wave life clocks | waves",
+         20: "nearest: group box test", 21: "shared leaf: group box test",
          16: "clocks/16 in nearest-hit traversal", 17: "clocks/16 in direct light + shadow"}
 
 
@@ -42,7 +43,7 @@ def main():
         rt.render_device(cam, fb.data_ptr(), args.w, mode=mode, spp_grid=args.spp_grid, stream=stream.cuda_stream)
         torch.cuda.synchronize()
         c = rt.ray_counts()
-        out = np.zeros(40, np.uint64)
+        out = np.zeros(44, np.uint64)
         L.mrt_debug_loop_counts(rt.h, out.ctypes.data_as(C.c_void_p))
         print("%s: %s" % (name, c))
         for s in sorted(SITES):
