@@ -9,6 +9,7 @@ import collections
 import csv
 import glob
 import json
+import re
 import os
 import shutil
 import sys
@@ -19,7 +20,9 @@ DOMINANT = {"c2": "render_tiles_resident<1>", "c2p": "render_tiles_global<0, 16>
 
 
 def short(name):
-    return name.replace("void mrt::", "").replace("mrt::", "").split("(")[0].replace(", false>", ">")
+    name = name.replace("void mrt::", "").replace("mrt::", "").split("(")[0]
+    # render_tiles_global<mode, stack entries, analytic objects, group boxes>: the last two do not name a configuration
+    return re.sub(r"render_tiles_global<(\d+), (\d+)[^>]*>", r"render_tiles_global<\1, \2>", name)
 
 
 def main():
