@@ -79,6 +79,9 @@ class Workload:
         self.name, self.W, self.H, self.mode, self.grid, self.cam = name, width, height, mode, grid, cam
         self.rank, self.world, self.torch, self.dist, self.split = rank, world, torch, dist, split
         self.gpu = device == "cuda"        # the CPU tests of the multi-rank logic pass a stand-in renderer and device="cpu"
+        # gloo (the one-GPU rehearsal) reads a device tensor from the host with no regard for the stream that is still
+        # writing it; RCCL's transfers are ordered behind the frame on the stream
+        self.host_transport = self.gpu and world > 1 and dist.get_backend() == "gloo"
         if rt is None:
             from raytracing_amd import Raytracer
             rt = Raytracer(width, height, device=torch.cuda.current_device())
@@ -140,6 +143,8 @@ class Workload:
             self.events.append((e0, e1))
         if self.world == 1:
             return
+        if self.host_transport:
+            stream.synchronize()
         if self.split == "frames":
             if self.rank == 0:
                 self.frames[0].copy_(fb)
@@ -465,6 +470,12 @@ def main():
             fr._finish_pending()
             torch.cuda.synchronize()
             ok = all(_fbsum(fr.frames[r].cpu().numpy().view(np.uint32)) == golden["c2_maze_1080p_recursive"]["fbsum"] for r in range(world))
+            if not ok:
+                for r in range(world):
+                    f = fr.frames[r].cpu().numpy().view(np.uint32)
+                    print("rehearsal: frame of rank %d: checksum %s, %d pixels differ from rank 0's, %d zero pixels" % (
+                        r, "ok" if _fbsum(f) == golden["c2_maze_1080p_recursive"]["fbsum"] else "WRONG",
+                        int((f != fr.frames[0].cpu().numpy().view(np.uint32)).sum()), int((f == 0).sum())), file=sys.stderr)
             print("rehearsal: %d gathered 1080p frames %s" % (world, "equal the oracle's frame" if ok else "DIFFER"), file=sys.stderr)
             assert ok
         del fr
