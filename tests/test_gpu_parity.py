@@ -525,6 +525,56 @@ def test_packet_frames_follow_the_eye_and_the_scene(maze_scene, maze_oracle):
     rt.close()
 
 
+def test_rays_in_the_plane_of_a_wall(maze_scene):
+    """Rays that run inside a wall's plane are where a triangle test's verdict is rounding noise, and where skipping
+    groups of a long leaf by their boxes must stand back (kernels.hip: not_grazing): lights placed exactly in the
+    planes of the three largest axis-parallel walls (shadow rays graze them), and eyes placed in those planes looking
+    along them.  Hit ids and packet pixels equal the oracle's; recursive pixels to 1/255."""
+    f = np.float32
+    tris = []
+    for m in maze_scene["meshes"]:
+        pos = np.asarray(m["pos"], f).reshape(-1, 3)
+        tris.append(pos[np.asarray(m["tri"], np.int32).reshape(-1, 3)])
+    T = np.concatenate(tris).astype(np.float64)
+    n = np.cross(T[:, 1] - T[:, 0], T[:, 2] - T[:, 0])
+    area = np.linalg.norm(n, axis=1)
+    walls = []
+    for axis in range(3):
+        flat = (np.abs(n[:, axis]) == area) & (area > 0)          # normal exactly along this axis
+        k = int(np.argmax(np.where(flat, area, 0)))
+        assert flat[k]
+        walls.append((axis, T[k]))
+    W, H = 256, 128
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(maze_scene)
+    ora = oracle_lib.Oracle()
+    ora.add_scene(maze_scene)
+    ora.build_bvh()
+    ora.set_threads(8)
+    for axis, tri in walls:
+        centre = tri.mean(0)
+        along = tri[1] - tri[0]
+        along /= np.linalg.norm(along)
+        in_plane = centre + 2.5 * along                             # a point of the wall's plane, beside the triangle
+        lights = np.array([[*in_plane, 1, 1, 1, 1]], f)
+        rt.set_lights(lights)
+        ora.set_lights(lights)
+        eye = centre - 3.0 * along
+        up_axis = (axis + 1) % 3
+        eye[up_axis] += 0.25
+        for cam in (pose_cam(POSES[0]), oracle_lib.lookat(tuple(eye), tuple(centre + 4.0 * along))):
+            cam = np.asarray(cam, f)
+            for mode in (MODE_PACKET, MODE_RECURSIVE):
+                fb, ids = rt.render(cam, mode=mode)
+                want = ora.render(cam, W, H, mode=mode)
+                assert np.array_equal(ids, want["ids"]), "hit ids differ on %d rays (axis %d)" % (int((ids != want["ids"]).sum()), axis)
+                if mode == MODE_PACKET:
+                    assert np.array_equal(fb, want["fb"])
+                else:
+                    assert colour_mismatch_fraction(fb, want["fb"]) <= 0.001
+    rt.close()
+
+
 @pytest.mark.parametrize("W,H", [(1000, 600), (16, 8), (256, 8)])
 def test_tile_order_from_previous_frame_changes_nothing(maze_scene, W, H):
     """The persistent kernel starts the tiles that were expensive in the previous launch of the same
