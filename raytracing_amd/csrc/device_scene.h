@@ -108,6 +108,12 @@ constexpr int kOrderHistBase = kStatBase + 16 * kStatSlots;
 constexpr int kProfSites = 22;
 constexpr int kProfBase = kOrderHistBase + 128;
 constexpr int kCounterSlots = kProfBase + 2 * kProfSites;
+#elif defined(MRT_WAVE_LIVES)
+// Diagnostic build only (make lives): the release kernels, and every persistent wave leaves {clock at entry, clock
+// at exit, tiles rendered} behind (scripts/wave_lives.py).
+constexpr int kLivesBase = kOrderHistBase + 128;
+constexpr int kLivesWaves = 4096;
+constexpr int kCounterSlots = kLivesBase + 3 * kLivesWaves;
 #else
 constexpr int kCounterSlots = kOrderHistBase + 128;
 #endif

@@ -1230,6 +1230,10 @@ __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_t
     const unsigned long long t_enter = __builtin_readcyclecounter();
     unsigned long long t_tiles = 0;
 #endif
+#ifdef MRT_WAVE_LIVES
+    const unsigned long long lives_enter = __builtin_readcyclecounter();
+    unsigned long long lives_tiles = 0;
+#endif
     const uint32_t n_node_v4 = 2u * (uint32_t)S.n_node_slots, n_tri = (uint32_t)S.n_tris;
     MRT_LDS v4f* l_nodes = (MRT_LDS v4f*)smem;
     MRT_LDS v4f* l_a = l_nodes + n_node_v4;
@@ -1286,7 +1290,19 @@ __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_t
 #ifdef MRT_LOOP_COUNTS
         t_tiles += __builtin_readcyclecounter() - t0;
 #endif
+#ifdef MRT_WAVE_LIVES
+        ++lives_tiles;
+#endif
     }
+#ifdef MRT_WAVE_LIVES
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (w < (uint32_t)kLivesWaves) {
+            unsigned long long* rec = F.counters + kLivesBase + 3 * w;
+            rec[0] = lives_enter; rec[1] = __builtin_readcyclecounter(); rec[2] = lives_tiles;
+        }
+    }
+#endif
 #ifdef MRT_LOOP_COUNTS
     if (lane == 0) {       // sites 18, 19: clocks until the scene copy is done | in tiles; the wave's whole life | 1
         const unsigned long long t_exit = __builtin_readcyclecounter();

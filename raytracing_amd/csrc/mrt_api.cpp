@@ -895,6 +895,16 @@ extern "C" int mrt_debug_loop_counts(mrt_ctx* c, uint64_t* out) {
     return MRT_OK;
 }
 #endif
+#ifdef MRT_WAVE_LIVES
+// diagnostic build only: out[3*w .. 3*w+2] = clock at entry, clock at exit, tiles rendered of persistent wave w of the last launch
+extern "C" int mrt_debug_wave_lives(mrt_ctx* c, uint64_t* out) {
+    if (!c || !out) return MRT_E_ARG;
+    MRT_HIP(c, hipSetDevice(c->device));
+    if (c->launched) MRT_HIP(c, hipEventSynchronize(c->last_done));
+    MRT_HIP(c, hipMemcpy(out, c->d_counters.p + kLivesBase, 3 * kLivesWaves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return MRT_OK;
+}
+#endif
 #if defined(MRT_LOOP_COUNTS) || defined(MRT_DEBUG_API)
 // diagnostic builds only: shader clocks per tile of the last persistent-kernel launch; returns the tile count
 extern "C" int mrt_debug_tile_costs(mrt_ctx* c, uint32_t* out, int capacity) {
