@@ -91,8 +91,7 @@ struct FrameDev {
     // The scene relative to this frame's eye, for the packet traversal of the primary rays (kernels.hip:
     // SceneGlobalEyeT, eye_relative_kernel); set for every packet-path launch of the one-wave-per-tile kernel.
     const float4* eye_nodes;
-    const float4* eye_t;
-    const float4* eye_q;
+    const float4* eye_tri;
     const float4* eye_g;
 };
 

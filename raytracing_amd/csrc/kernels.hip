@@ -107,6 +107,9 @@ struct SceneGlobalT {
     __device__ __forceinline__ bool has_groups() const { return G; }
     __device__ __forceinline__ v4u group(uint32_t g) const { return triG[g]; }
     __device__ __forceinline__ v4f node(uint32_t i) const { return nodes[i]; }
+    // the two children of an inner node (slots L and L + 1): four records read through ONE pointer, so that the
+    // compiler sees 64 consecutive bytes (one wide load) instead of four indices that might wrap
+    __device__ __forceinline__ const v4f* siblings(uint32_t L) const { return nodes + 2 * (size_t)L; }
     __device__ __forceinline__ v4f tri_a(uint32_t k) const { return triA[k]; }
     __device__ __forceinline__ v4f tri_b(uint32_t k) const { return triB[k]; }
     __device__ __forceinline__ v2f tri_c(uint32_t k) const { return triC[k]; }
@@ -123,12 +126,13 @@ struct SceneGlobalT {
 // them (scalar loads, like the nodes and triangles themselves) instead of issuing those subtractions,
 // the cross product and the dot product in every wave:
 //   eyeNodes[2i], [2i+1] = {min - O, bits(firstLeft)}, {max - O, bits(count)}
-//   eyeT[k] = {tvec.xyz, dot(e2, qvec)}      eyeQ[k] = {qvec.xyz, bits(triangle id)}
+//   eyeTri[4k .. 4k+3] = {e1.xyz, e2.x}, {e2.yz, tvec.xy}, {tvec.z, dot(e2, qvec), qvec.xy}, {qvec.z, bits(triangle id), 0, 0}
+//                        (one 64-byte record per triangle: one address, the first half decides "faces away")
 //   eyeG[2g], [2g+1] = {lo - O, 0}, {hi - O, 0} of group box g (device_scene.h: triG)
 template <bool G>
 struct SceneGlobalEyeT : SceneGlobalT<G> {
     static constexpr bool kEyeRelative = true;
-    const v4f* eyeNodes; const v4f* eyeT; const v4f* eyeQ;
+    const v4f* eyeNodes; const v4f* eyeTri;
     const v4f* eyeG;      // [2g], [2g+1] = the group box's corners minus O (nullptr: no group boxes)
 };
 struct SceneLds {
@@ -140,6 +144,7 @@ struct SceneLds {
     __device__ __forceinline__ bool has_groups() const { return groups; }
     __device__ __forceinline__ v4u group(uint32_t g) const { return triG[g]; }
     __device__ __forceinline__ v4f node(uint32_t i) const { return nodes[i]; }
+    __device__ __forceinline__ MRT_LDS const v4f* siblings(uint32_t L) const { return nodes + 2 * L; }
     __device__ __forceinline__ v4f tri_a(uint32_t k) const { return triA[k]; }
     __device__ __forceinline__ v4f tri_b(uint32_t k) const { return triB[k]; }
     __device__ __forceinline__ v2f tri_c(uint32_t k) const { return triC[k]; }
@@ -301,16 +306,18 @@ __device__ __forceinline__ void tri_test(v4f A, v4f B, v2f C, f3 O, f3 D, float&
     tri_decide<WAVE_REJECT>(det, un, vn, tn, __float_as_uint(C.y), t, h, wd);
 }
 
-// The same test for a ray that starts at the eye, from the frame's precomputed terms (SceneGlobalEyeT).
-__device__ __forceinline__ void tri_test_eye(v4f A, v2f Blo, v4f T, v4f Q, f3 D, float& t, Hit& h, Watch& wd) {
-    const f3 e1 = {A.x, A.y, A.z}, e2 = {A.w, Blo.x, Blo.y};
+// The same test for a ray that starts at the eye, from the frame's precomputed record (SceneGlobalEyeT: eyeTri).
+__device__ __forceinline__ void tri_test_eye(const v4f* rec, f3 D, float& t, Hit& h, Watch& wd) {
+    const v4f A = rec[0], B = rec[1];
+    const f3 e1 = {A.x, A.y, A.z}, e2 = {A.w, B.x, B.y};
     const f3 pvec = cross(D, e2);
     const float det = dot(e1, pvec);
     if (!__any(!(det < -kEpsilon))) return;
     MRT_TICK(wd, 6);
-    const float un = dot(f3{T.x, T.y, T.z}, pvec);
-    const float vn = dot(D, f3{Q.x, Q.y, Q.z});
-    tri_decide<true>(det, un, vn, T.w, __float_as_uint(Q.w), t, h, wd);
+    const v4f C = rec[2], E = rec[3];
+    const float un = dot(f3{B.z, B.w, C.x}, pvec);
+    const float vn = dot(D, f3{C.z, C.w, E.x});
+    tri_decide<true>(det, un, vn, C.y, __float_as_uint(E.y), t, h, wd);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -445,14 +452,14 @@ __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f
                     if (sc.has_groups() && count >= (uint32_t)MRT_GROUP_MIN) {
                         walk_leaf_by_groups<SC::kEyeRelative>(sc, first, count, O, rg, rg_ok, t, wd, [&](uint32_t k) {
                             MRT_TICK(wd, 10);
-                            if constexpr (SC::kEyeRelative) tri_test_eye(sc.tri_a(k), sc.tri_b_lo(k), sc.eyeT[k], sc.eyeQ[k], D, t, h, wd);
+                            if constexpr (SC::kEyeRelative) tri_test_eye(sc.eyeTri + 4 * (size_t)k, D, t, h, wd);
                             else tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
                             return false;
                         });
                     } else if constexpr (SC::kEyeRelative) {
                         for (uint32_t k = first; k < first + count; ++k) {
                             MRT_TICK(wd, 10);
-                            tri_test_eye(sc.tri_a(k), sc.tri_b_lo(k), sc.eyeT[k], sc.eyeQ[k], D, t, h, wd);
+                            tri_test_eye(sc.eyeTri + 4 * (size_t)k, D, t, h, wd);
                         }
                     } else if constexpr (SC::kPrefetchLeaf) {
                         v4f A = sc.tri_a(first), B = sc.tri_b(first);
@@ -477,7 +484,9 @@ __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f
             }
             MRT_TICK(wd, 9);
             const uint32_t L = first, R = first + 1;
-            const v4f l0 = box(2 * L), l1 = box(2 * L + 1), r0 = box(2 * R), r1 = box(2 * R + 1);
+            v4f l0, l1, r0, r1;
+            if constexpr (SC::kEyeRelative) { const v4f* p = sc.eyeNodes + 2 * (size_t)L; l0 = p[0]; l1 = p[1]; r0 = p[2]; r1 = p[3]; }
+            else { const auto p = sc.siblings(L); l0 = p[0]; l1 = p[1]; r0 = p[2]; r1 = p[3]; }
             float tnl, tfl, tnr, tfr;
             terms(xyz(l0), xyz(l1), tnl, tfl);
             terms(xyz(r0), xyz(r1), tnr, tfr);
@@ -535,7 +544,8 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
         while (alive && count == 0) {
             MRT_TICK(wd, 0);
             const uint32_t L = first, Rr = first + 1;
-            const v4f l0 = sc.node(2 * L), l1 = sc.node(2 * L + 1), r0 = sc.node(2 * Rr), r1 = sc.node(2 * Rr + 1);
+            const auto pair = sc.siblings(L);
+            const v4f l0 = pair[0], l1 = pair[1], r0 = pair[2], r1 = pair[3];
             bool leftN, rightN;
             float tNear, tNear2;
             slab_div_pair(l0, l1, r0, r1, R, shortcut, t, leftN, rightN, tNear, tNear2);
@@ -667,7 +677,8 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
             found = __ballot(h.tri >= 0);
         } else {
             const uint32_t L = first, Rr = first + 1;
-            const v4f l0 = sc.node(2 * L), l1 = sc.node(2 * L + 1), r0 = sc.node(2 * Rr), r1 = sc.node(2 * Rr + 1);
+            const auto pair = sc.siblings(L);
+            const v4f l0 = pair[0], l1 = pair[1], r0 = pair[2], r1 = pair[3];
             MRT_TICK(wd, 4);
             bool leftN, rightN;
             const bool sure = shortcut && slab_pair_shadow_interval(l0, l1, r0, r1, R, leftN, rightN);
@@ -1127,8 +1138,8 @@ __global__ __launch_bounds__(64, MODE == 0 ? MRT_PACKET_WAVES : MRT_RECURSIVE_WA
     const int tile = ((q / kXcdRun) * kXcds + b % kXcds) * kXcdRun + q % kXcdRun;
     if (tile >= F.n_tiles) return;
     if constexpr (MODE == 0) {
-        const SceneGlobalEyeT<G> sc{global_scene<G>(S), reinterpret_cast<const v4f*>(F.eye_nodes), reinterpret_cast<const v4f*>(F.eye_t),
-                                reinterpret_cast<const v4f*>(F.eye_q), reinterpret_cast<const v4f*>(F.eye_g)};
+        const SceneGlobalEyeT<G> sc{global_scene<G>(S), reinterpret_cast<const v4f*>(F.eye_nodes), reinterpret_cast<const v4f*>(F.eye_tri),
+                                    reinterpret_cast<const v4f*>(F.eye_g)};
         render_tile<MODE, OBJ>(sc, S, F, tile, lane, (MRT_LDS uint32_t*)lds_stack + lane);
     } else {
         render_tile<MODE, OBJ>(global_scene<G>(S), S, F, tile, lane, (MRT_LDS uint32_t*)lds_stack + lane);
@@ -1137,8 +1148,7 @@ __global__ __launch_bounds__(64, MODE == 0 ? MRT_PACKET_WAVES : MRT_RECURSIVE_WA
 
 // The frame's eye-relative copy of the nodes and triangles (SceneGlobalEyeT): one thread per node record and
 // per triangle, the operations of the box and triangle tests in their order.
-__global__ __launch_bounds__(256) void eye_relative_kernel(SceneDev S, float ox, float oy, float oz, float4* eye_nodes, float4* eye_t, float4* eye_q,
-                                                           float4* eye_g) {
+__global__ __launch_bounds__(256) void eye_relative_kernel(SceneDev S, float ox, float oy, float oz, float4* eye_nodes, float4* eye_tri, float4* eye_g) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const f3 O = {ox, oy, oz};
     if (i < 2u * (uint32_t)S.n_node_slots) {
@@ -1153,8 +1163,10 @@ __global__ __launch_bounds__(256) void eye_relative_kernel(SceneDev S, float ox,
         const f3 tvec = O - p0;
         const f3 qvec = cross(tvec, e1);
         const float tn = dot(e2, qvec);
-        eye_t[i] = make_float4(tvec.x, tvec.y, tvec.z, tn);
-        eye_q[i] = make_float4(qvec.x, qvec.y, qvec.z, C.y);
+        eye_tri[4 * (size_t)i] = A;
+        eye_tri[4 * (size_t)i + 1] = make_float4(B.x, B.y, tvec.x, tvec.y);
+        eye_tri[4 * (size_t)i + 2] = make_float4(tvec.z, tn, qvec.x, qvec.y);
+        eye_tri[4 * (size_t)i + 3] = make_float4(qvec.z, C.y, 0.0f, 0.0f);
     }
     if (S.triG && i < ((uint32_t)S.n_tris + 3u) / 4u) {
         const uint4 g = S.triG[i];
@@ -1458,10 +1470,10 @@ hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool re
     return mode == 0 ? launch_global_mode<0>(S, F, stream) : launch_global_mode<1>(S, F, stream);
 }
 
-hipError_t launch_eye_relative(const SceneDev& S, const float eye[3], float4* eye_nodes, float4* eye_t, float4* eye_q, float4* eye_g, hipStream_t stream) {
+hipError_t launch_eye_relative(const SceneDev& S, const float eye[3], float4* eye_nodes, float4* eye_tri, float4* eye_g, hipStream_t stream) {
     const uint32_t n = std::max(2u * (uint32_t)S.n_node_slots, (uint32_t)S.n_tris);
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(eye_relative_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, S, eye[0], eye[1], eye[2], eye_nodes, eye_t, eye_q, eye_g);
+    hipLaunchKernelGGL(eye_relative_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, S, eye[0], eye[1], eye[2], eye_nodes, eye_tri, eye_g);
     return hipGetLastError();
 }
 

@@ -21,7 +21,7 @@
 
 namespace mrt {
 hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool resident, int n_cus, int resident_threads, hipStream_t stream);
-hipError_t launch_eye_relative(const SceneDev& S, const float eye[3], float4* eye_nodes, float4* eye_t, float4* eye_q, float4* eye_g, hipStream_t stream);
+hipError_t launch_eye_relative(const SceneDev& S, const float eye[3], float4* eye_nodes, float4* eye_tri, float4* eye_g, hipStream_t stream);
 hipError_t prepare_render_kernels();
 hipError_t launch_depth_view(const SceneDev& S, const FrameDev& F, hipStream_t stream);
 hipError_t launch_order_tiles(const uint32_t* cost, uint32_t* packed, uint32_t* hist, uint32_t* order, int n, hipStream_t stream);
@@ -117,7 +117,7 @@ struct mrt_ctx {
     bool has_groups = false;
     // nodes and triangles relative to the eye of the last packet-path frame (kernels.hip: SceneGlobalEyeT), sized at
     // scene upload; eye_key = the eye position and scene_serial they were made for
-    DevBuf<float4> d_eye_nodes, d_eye_t, d_eye_q, d_eye_g;
+    DevBuf<float4> d_eye_nodes, d_eye_tri, d_eye_g;
     uint32_t eye_key[4] = {0, 0, 0, 0};
     bool resident = false;      // scene small enough for the LDS-resident kernel
     unsigned scene_serial = 0;  // counts scene uploads
@@ -324,10 +324,10 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
         memcpy(key, F.cam, 12);
         key[3] = c->scene_serial;
         if (memcmp(key, c->eye_key, sizeof key) != 0) {
-            MRT_HIP(c, launch_eye_relative(c->scene, F.cam, c->d_eye_nodes.p, c->d_eye_t.p, c->d_eye_q.p, c->d_eye_g.p, stream));
+            MRT_HIP(c, launch_eye_relative(c->scene, F.cam, c->d_eye_nodes.p, c->d_eye_tri.p, c->d_eye_g.p, stream));
             memcpy(c->eye_key, key, sizeof key);
         }
-        F.eye_nodes = c->d_eye_nodes.p; F.eye_t = c->d_eye_t.p; F.eye_q = c->d_eye_q.p; F.eye_g = c->d_eye_g.p;
+        F.eye_nodes = c->d_eye_nodes.p; F.eye_tri = c->d_eye_tri.p; F.eye_g = c->d_eye_g.p;
     }
     MRT_HIP(c, launch_render(c->scene, F, mode, resident, c->n_cus, env_int("MRT_RESIDENT_THREADS", kResidentThreads), stream));
     MRT_HIP(c, hipEventRecord(c->last_done, stream));
@@ -674,8 +674,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     }
     MRT_HIP(c, c->d_lights.upload(c->lights, c->stream));
     MRT_HIP(c, c->d_eye_nodes.ensure(std::max<size_t>(1, 2 * slots)));
-    MRT_HIP(c, c->d_eye_t.ensure(std::max<size_t>(1, B.n_tris)));
-    MRT_HIP(c, c->d_eye_q.ensure(std::max<size_t>(1, B.n_tris)));
+    MRT_HIP(c, c->d_eye_tri.ensure(std::max<size_t>(4, 4 * (size_t)B.n_tris)));
     MRT_HIP(c, c->d_eye_g.ensure(std::max<size_t>(2, 2 * n_groups)));
     stage("upload ray-path arrays");
     if (int rc = raster_upload(c->raster, meshes, n_meshes, c->stream, err)) return fail(c, rc, err);
