@@ -13,6 +13,9 @@
 //             triC[k] = {p0.z, bits(triangle id)}      (raytracer.cpp:289-290)
 //           The edges come first: the first 24 bytes decide whether the triangle faces away from a
 //           ray, which dismisses about half of all tests before the rest is read.
+//   triM  : the triangle arrays once more as ONE record of 3 float4 per leaf-order slot, {triA, triB, {triC, 0, 0}}:
+//           the traversals in which all lanes test the same triangle (packet leaves, shadow rays) of the
+//           global-memory kernels read a triangle through one address instead of three.
 //   triG  : one uint4 per group of four consecutive leaf-order slots (4g .. 4g+3, whatever leaves they belong
 //           to): a box around those triangles, padded by 2^-12 of the scene's largest coordinate and rounded
 //           outwards to binary16: {lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16, 0}.  A ray that
@@ -42,6 +45,7 @@ struct SceneDev {
     const float4* triB;
     const float2* triC;
     const uint4* triG;
+    const float4* triM;
     const float4* attr;
     const int4* tex;
     const uint8_t* texels;

@@ -104,6 +104,8 @@ struct SceneGlobalT {
     static constexpr bool kShadowGroups = true;      // the shared shadow traversal consults the group boxes
     const v4f* nodes; const v4f* triA; const v4f* triB; const v2f* triC;
     const v4u* triG;      // group boxes (device_scene.h)
+    const v4f* triM;      // the same triangles as one 48-byte record each (device_scene.h): one address per test
+    static constexpr bool kMergedTris = true;
     __device__ __forceinline__ bool has_groups() const { return G; }
     __device__ __forceinline__ v4u group(uint32_t g) const { return triG[g]; }
     __device__ __forceinline__ v4f node(uint32_t i) const { return nodes[i]; }
@@ -141,6 +143,7 @@ struct SceneLds {
     static constexpr bool kShadowGroups = true;
     MRT_LDS const v4f* nodes; MRT_LDS const v4f* triA; MRT_LDS const v4f* triB; MRT_LDS const v2f* triC;
     MRT_LDS const v4u* triG; bool groups;
+    static constexpr bool kMergedTris = false;
     __device__ __forceinline__ bool has_groups() const { return groups; }
     __device__ __forceinline__ v4u group(uint32_t g) const { return triG[g]; }
     __device__ __forceinline__ v4f node(uint32_t i) const { return nodes[i]; }
@@ -306,6 +309,18 @@ __device__ __forceinline__ void tri_test(v4f A, v4f B, v2f C, f3 O, f3 D, float&
     tri_decide<WAVE_REJECT>(det, un, vn, tn, __float_as_uint(C.y), t, h, wd);
 }
 
+// A triangle all calling lanes test together, read the way the scene's home allows: one record, or three arrays.
+template <class SC>
+__device__ __forceinline__ void tri_test_shared(const SC& sc, uint32_t k, f3 O, f3 D, float& t, Hit& h, Watch& wd) {
+    if constexpr (SC::kMergedTris) {
+        const v4f* rec = sc.triM + 3 * (size_t)k;
+        const v4f C = rec[2];
+        tri_test<true>(rec[0], rec[1], v2f{C.x, C.y}, O, D, t, h, wd);
+    } else {
+        tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
+    }
+}
+
 // The same test for a ray that starts at the eye, from the frame's precomputed record (SceneGlobalEyeT: eyeTri).
 __device__ __forceinline__ void tri_test_eye(const v4f* rec, f3 D, float& t, Hit& h, Watch& wd) {
     const v4f A = rec[0], B = rec[1];
@@ -438,7 +453,9 @@ __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f
         const uint32_t e = work.pop();
         uint32_t node = e >> 6;
         const int f = (int)(e & 63u);
-        const v4f n0 = box(2 * node), n1 = box(2 * node + 1);
+        v4f n0, n1;
+        if constexpr (SC::kEyeRelative) { const v4f* p = sc.eyeNodes + 2 * (size_t)node; n0 = p[0]; n1 = p[1]; }
+        else { n0 = box(2 * node); n1 = box(2 * node + 1); }
         float tn, tf;
         terms(xyz(n0), xyz(n1), tn, tf);
         const bool pass = slab_pass(tn, tf, t);
@@ -453,7 +470,7 @@ __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f
                         walk_leaf_by_groups<SC::kEyeRelative>(sc, first, count, O, rg, rg_ok, t, wd, [&](uint32_t k) {
                             MRT_TICK(wd, 10);
                             if constexpr (SC::kEyeRelative) tri_test_eye(sc.eyeTri + 4 * (size_t)k, D, t, h, wd);
-                            else tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
+                            else tri_test_shared(sc, k, O, D, t, h, wd);
                             return false;
                         });
                     } else if constexpr (SC::kEyeRelative) {
@@ -476,7 +493,7 @@ __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f
                     } else {
                         for (uint32_t k = first; k < first + count; ++k) {
                             MRT_TICK(wd, 10);
-                            tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
+                            tri_test_shared(sc, k, O, D, t, h, wd);
                         }
                     }
                 }
@@ -650,7 +667,7 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
                 if (SC::kShadowGroups && sc.has_groups() && count >= (uint32_t)MRT_GROUP_MIN) {
                     walk_leaf_by_groups<false>(sc, first, count, O, R.r, r_ok, t, wd, [&](uint32_t k) {
                         MRT_TICK(wd, 5);
-                        if (h.tri < 0) tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
+                        if (h.tri < 0) tri_test_shared(sc, k, O, D, t, h, wd);
                         return !__any(h.tri < 0);
                     });
                 } else if constexpr (SC::kPrefetchLeaf) {
@@ -669,7 +686,7 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
                 } else {
                     for (uint32_t k = first; k < first + count; ++k) {
                         MRT_TICK(wd, 5);
-                        if (h.tri < 0) tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
+                        if (h.tri < 0) tri_test_shared(sc, k, O, D, t, h, wd);
                         if (!__any(h.tri < 0)) break;
                     }
                 }
@@ -1116,7 +1133,7 @@ template <bool G>
 __device__ __forceinline__ SceneGlobalT<G> global_scene(const SceneDev& S) {
     return SceneGlobalT<G>{reinterpret_cast<const v4f*>(S.nodes), reinterpret_cast<const v4f*>(S.triA),
                        reinterpret_cast<const v4f*>(S.triB), reinterpret_cast<const v2f*>(S.triC),
-                       reinterpret_cast<const v4u*>(S.triG)};
+                       reinterpret_cast<const v4u*>(S.triG), reinterpret_cast<const v4f*>(S.triM)};
 }
 
 // Scene in global memory: one 64-thread workgroup (one wave) per tile.  SD = stack entries.

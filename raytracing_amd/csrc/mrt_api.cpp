@@ -114,6 +114,7 @@ struct mrt_ctx {
     DevBuf<float4> d_nodes, d_triA, d_triB, d_attr, d_lights;
     DevBuf<float2> d_triC;
     DevBuf<uint4> d_triG;
+    DevBuf<float4> d_triM;
     bool has_groups = false;
     // nodes and triangles relative to the eye of the last packet-path frame (kernels.hip: SceneGlobalEyeT), sized at
     // scene upload; eye_key = the eye position and scene_serial they were made for
@@ -181,6 +182,7 @@ void refresh_scene_view(mrt_ctx* c) {
     SceneDev& S = c->scene;
     S.nodes = c->d_nodes.p; S.triA = c->d_triA.p; S.triB = c->d_triB.p; S.triC = c->d_triC.p; S.attr = c->d_attr.p;
     S.triG = c->has_groups ? c->d_triG.p : nullptr;
+    S.triM = c->d_triM.p;
     S.tex = c->d_tex.p; S.texels = c->d_texels.p; S.pal = c->d_pal.p;
     S.lights = c->d_lights.p;
     S.objects = c->objects.empty() ? nullptr : c->d_objects.p;
@@ -566,6 +568,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     const bool coords_ok = coords_all_ok;
     std::vector<float4> triA(B.n_tris), triB(B.n_tris), attr(4 * (size_t)B.n_tris);
     std::vector<float2> triC(B.n_tris);
+    std::vector<float4> triM(3 * (size_t)B.n_tris);
     parallel_for(B.n_tris, [&](size_t b, size_t e) {
         for (size_t k = b; k < e; ++k) {
             const uint32_t id = B.idx[k];
@@ -574,6 +577,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
             triA[k] = make_float4(e1.x, e1.y, e1.z, e2.x);
             triB[k] = make_float4(e2.y, e2.z, t.p0.x, t.p0.y);
             triC[k] = make_float2(t.p0.z, bits2f(id));
+            triM[3 * k] = triA[k]; triM[3 * k + 1] = triB[k]; triM[3 * k + 2] = make_float4(t.p0.z, bits2f(id), 0.0f, 0.0f);
         }
         for (size_t id = b; id < e; ++id) {
             const HostTri& t = B.tris[id];
@@ -665,6 +669,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     MRT_HIP(c, c->d_triA.upload(triA, c->stream));
     MRT_HIP(c, c->d_triB.upload(triB, c->stream));
     MRT_HIP(c, c->d_triC.upload(triC, c->stream));
+    MRT_HIP(c, c->d_triM.upload(triM, c->stream));
     if (c->has_groups) MRT_HIP(c, c->d_triG.upload(triG, c->stream));
     MRT_HIP(c, c->d_attr.upload(attr, c->stream));
     if (!refit) {
