@@ -1052,8 +1052,8 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
             ar += __shfl_xor(ar, o * 8, 64);  gb += __shfl_xor(gb, o * 8, 64);
         }
         if (((lane & 7) % g) == 0 && ((lane >> 3) % g) == 0) {
-            const uint32_t n = (uint32_t)(g * g);
-            const uint32_t out = (((ar >> 16) / n) << 24) | (((ar & 0xffffu) / n) << 16) | (((gb >> 16) / n) << 8) | ((gb & 0xffffu) / n);
+            const int sh = 2 * (__ffs(g) - 1);          // g is 2, 4 or 8: dividing by g * g is a shift
+            const uint32_t out = (((ar >> 16) >> sh) << 24) | (((ar & 0xffffu) >> sh) << 16) | (((gb >> 16) >> sh) << 8) | ((gb & 0xffffu) >> sh);
             F.fb[(size_t)(y_store / g) * F.pitch + (x / g)] = out;
         }
     }
