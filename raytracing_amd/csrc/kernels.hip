@@ -402,7 +402,8 @@ __device__ __forceinline__ void walk_leaf_by_groups(const SC& sc, uint32_t first
             MRT_TICK(wd, 21);
             bool touched;
             if constexpr (EYE) {
-                const v4f glo = sc.eyeG[2 * (k >> 2)], ghi = sc.eyeG[2 * (k >> 2) + 1];
+                const v4f* gbox = sc.eyeG + 2 * (size_t)(k >> 2);
+                const v4f glo = gbox[0], ghi = gbox[1];
                 touched = group_touched_rel(xyz(glo), xyz(ghi), r, t);
             } else {
                 touched = group_touched(sc.group(k >> 2), O, r, t);
