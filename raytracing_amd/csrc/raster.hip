@@ -118,93 +118,141 @@ __device__ __forceinline__ ClipPoly clip_against(const ClipPoly& in, f3 normal, 
     return out;
 }
 
+// Second half of the set-up of one polygon (3 to NMAX corners, in the clip's output order): palette level, screen
+// coordinates, attribute planes, pixel box and the edge table, written into the record T (which lives in LDS: its
+// edge arrays are filled at a running index).  NMAX = 3 is the triangle no clip plane touched: every index is then a
+// compile-time constant and the corner arrays stay in registers; the five-corner form indexes them at run time and
+// the compiler keeps them in private memory, which only the lanes with a clipped triangle then touch.
+template <int NMAX>
+__device__ __forceinline__ void setup_polygon(const f3* p, const f2* t, int nin, f3 Nt, int texture, int W, int H, RasterTri& T) {
+    T.level = (int)(gmax(0.0f, Nt.z) * 31);                        // rasterizer.cpp:136
+    T.texture = texture;
+    float sx[NMAX], sy[NMAX], iz[NMAX], uz[NMAX], vz[NMAX];
+    float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+#pragma unroll
+    for (int v = 0; v < NMAX; ++v) {
+        if (v >= nin) break;
+        const f3 q = p[v];
+        sx[v] = ((q.x * W) / -q.z) + W / 2;                         // :140-141
+        sy[v] = ((q.y * W) / q.z) + H / 2;
+        iz[v] = 1.0f / q.z;                                        // :151
+        uz[v] = t[v].x * iz[v];                                    // :152-153
+        vz[v] = t[v].y * iz[v];
+        xmin = fminf(xmin, sx[v]); xmax = fmaxf(xmax, sx[v]);
+        ymin = fminf(ymin, sy[v]); ymax = fmaxf(ymax, sy[v]);
+    }
+    // affine attribute planes through the polygon's widest vertex triple
+    int b = 1, c = 2;
+    if (NMAX > 3) {
+        float best = 0.0f;
+        for (int j = 1; j < nin; ++j)
+            for (int k = j + 1; k < nin; ++k) {
+                const float ar = fabsf((sx[j] - sx[0]) * (sy[k] - sy[0]) - (sx[k] - sx[0]) * (sy[j] - sy[0]));
+                if (ar > best) { best = ar; b = j; c = k; }
+            }
+    }
+    const double x1 = (double)sx[b] - sx[0], y1 = (double)sy[b] - sy[0], x2 = (double)sx[c] - sx[0], y2 = (double)sy[c] - sy[0];
+    const double det = x1 * y2 - x2 * y1;
+    if (!(det != 0.0 && xmax >= 0.0f && ymax >= 1.0f && xmin < (float)W && ymin < (float)H)) return;
+    auto plane = [&](const float* a, float& A, float& B, float& C) {
+        const double d1 = (double)a[b] - a[0], d2 = (double)a[c] - a[0];
+        const double pa = (d1 * y2 - d2 * y1) / det, pb = (x1 * d2 - x2 * d1) / det;
+        A = (float)pa; B = (float)pb; C = (float)((double)a[0] - pa * sx[0] - pb * sy[0]);
+    };
+    float A, B, C;
+    plane(iz, A, B, C); T.zA = A; T.zB = B; T.zC = C;
+    plane(uz, A, B, C); T.uA = A; T.uB = B; T.uC = C;
+    plane(vz, A, B, C); T.vA = A; T.vB = B; T.vC = C;
+    // rows max(1,(int)y0+1) .. min(H-2,(int)y1), columns (int)x0+1 .. min(W-2,(int)x1): :149, :170
+    const int by0 = max(1, (int)fmaxf(ymin, -1.0f) + 1), by1 = min(H - 2, (int)fminf(ymax, (float)H));
+    const int bx0 = max(0, (int)fmaxf(xmin, -1.0f) + 1), bx1 = min(W - 2, (int)fminf(xmax, (float)W));
+    T.y0 = by0; T.y1 = by1; T.x0 = bx0; T.x1 = bx1;
+    if (!(by0 <= by1 && bx0 <= bx1)) return;
+    int ne = 0;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {                               // rasterizer.cpp:143-151
+        if (j >= nin) break;
+        const int j2 = (j + 1 == nin) ? 0 : j + 1;
+        float xa = sx[j], ya = sy[j], xb = sx[j2], yb = sy[j2];       // the edge, oriented top to bottom
+        if (ya > yb) { float h = xa; xa = xb; xb = h; h = ya; ya = yb; yb = h; }
+        if ((ya == yb) || (ya >= H) || (yb < 1)) continue;
+        const float rydiff = 1.0f / (yb - ya);
+        const int r0 = max(1, (int)ya + 1), r1 = min(H - 2, (int)yb);
+        if (r0 > r1) continue;
+        T.ex[ne] = xa; T.ey[ne] = ya; T.dx[ne] = (xb - xa) * rydiff;
+        T.iy0[ne] = r0; T.iy1[ne] = r1;
+        ++ne;
+    }
+    T.n = ne;
+}
+
 __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* pos, const float* uv, const float* N, const int32_t* tri,
                                                      const int32_t* tri_mesh, const int32_t* mesh_tex, RasterTri* out, uint32_t n_tris, uint2* bins, int tiles_x,
                                                      uint32_t* tile_count, uint32_t* big, uint32_t* big_count, float z_near, float z_scale) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_range = i < n_tris;
-    RasterTri T;
-    T.n = 0;
-    const int texture = in_range ? mesh_tex[tri_mesh[i]] : -1;       // -1 when the mesh is culled or has no texture
-    if (texture >= 0) {
-        const int W = F.W, H = F.H;
-        m4 M;
-        memcpy(&M, F.M, 64);
-        const f3 Nt = mul3(M, f3{N[3 * i], N[3 * i + 1], N[3 * i + 2]});       // rasterizer.cpp:112
-        ClipPoly poly;
-        poly.n = 0;
-        for (int v = 0; v < 3; ++v) {
-            const int vi = tri[3 * i + v];
-            poly.add(xform(F.M, f3{pos[3 * vi], pos[3 * vi + 1], pos[3 * vi + 2]}), f2{uv[2 * vi], uv[2 * vi + 1]});   // rasterizer.cpp:100
-        }
-        if (!(dot(poly.p[0], Nt) > 0)) {                                       // back-face cull, :113
-            for (int plane = 0; plane < 2; ++plane)
-                poly = clip_against(poly, f3{F.frustum[plane][0], F.frustum[plane][1], F.frustum[plane][2]}, F.frustum[plane][3]);
-            const int nin = poly.n;
-            if (nin >= 3 && nin <= 5) {
-                T.level = (int)(gmax(0.0f, Nt.z) * 31);                        // :136
-                T.texture = texture;
-                float sx[5], sy[5], iz[5], uz[5], vz[5];
-                float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
-                for (int v = 0; v < nin; ++v) {
-                    const f3 p = poly.p[v];
-                    sx[v] = ((p.x * W) / -p.z) + W / 2;                         // :140-141
-                    sy[v] = ((p.y * W) / p.z) + H / 2;
-                    iz[v] = 1.0f / p.z;                                        // :151
-                    uz[v] = poly.t[v].x * iz[v];                               // :152-153
-                    vz[v] = poly.t[v].y * iz[v];
-                    xmin = fminf(xmin, sx[v]); xmax = fmaxf(xmax, sx[v]);
-                    ymin = fminf(ymin, sy[v]); ymax = fmaxf(ymax, sy[v]);
-                }
-                // affine attribute planes through the polygon's widest vertex triple
-                int b = 1, c = 2;
-                float best = 0.0f;
-                for (int j = 1; j < nin; ++j)
-                    for (int k = j + 1; k < nin; ++k) {
-                        const float ar = fabsf((sx[j] - sx[0]) * (sy[k] - sy[0]) - (sx[k] - sx[0]) * (sy[j] - sy[0]));
-                        if (ar > best) { best = ar; b = j; c = k; }
-                    }
-                const double x1 = (double)sx[b] - sx[0], y1 = (double)sy[b] - sy[0], x2 = (double)sx[c] - sx[0], y2 = (double)sy[c] - sy[0];
-                const double det = x1 * y2 - x2 * y1;
-                if (det != 0.0 && xmax >= 0.0f && ymax >= 1.0f && xmin < (float)W && ymin < (float)H) {
-                    auto plane = [&](const float* a, float& A, float& B, float& C) {
-                        const double d1 = (double)a[b] - a[0], d2 = (double)a[c] - a[0];
-                        const double pa = (d1 * y2 - d2 * y1) / det, pb = (x1 * d2 - x2 * d1) / det;
-                        A = (float)pa; B = (float)pb; C = (float)((double)a[0] - pa * sx[0] - pb * sy[0]);
-                    };
-                    plane(iz, T.zA, T.zB, T.zC);
-                    plane(uz, T.uA, T.uB, T.uC);
-                    plane(vz, T.vA, T.vB, T.vC);
-                    // rows max(1,(int)y0+1) .. min(H-2,(int)y1), columns (int)x0+1 .. min(W-2,(int)x1): :149, :170
-                    T.y0 = max(1, (int)fmaxf(ymin, -1.0f) + 1);
-                    T.y1 = min(H - 2, (int)fminf(ymax, (float)H));
-                    T.x0 = max(0, (int)fmaxf(xmin, -1.0f) + 1);
-                    T.x1 = min(W - 2, (int)fminf(xmax, (float)W));
-                    if (T.y0 <= T.y1 && T.x0 <= T.x1) {
-                        int ne = 0;
-                        for (int j = 0; j < nin; ++j) {                      // rasterizer.cpp:143-151
-                            int a = j, b2 = (j + 1 == nin) ? 0 : j + 1;
-                            if (sy[a] > sy[b2]) { const int h = a; a = b2; b2 = h; }
-                            const float ya = sy[a], yb = sy[b2];
-                            if ((ya == yb) || (ya >= H) || (yb < 1)) continue;
-                            const float rydiff = 1.0f / (yb - ya);
-                            T.ex[ne] = sx[a]; T.ey[ne] = ya; T.dx[ne] = (sx[b2] - sx[a]) * rydiff;
-                            T.iy0[ne] = max(1, (int)ya + 1); T.iy1[ne] = min(H - 2, (int)yb);
-                            if (T.iy0[ne] <= T.iy1[ne]) ++ne;
-                        }
-                        T.n = ne;
-                    }
-                }
-            }
-        }
-    }
-    // The 164-byte records of a workgroup's 256 triangles are contiguous in memory: they go through LDS so that
-    // the workgroup writes them as whole cache lines instead of each thread scattering 41 words.  A culled
+    // The 164-byte records of a workgroup's 256 triangles are contiguous in memory: they are built in LDS and the
+    // workgroup then writes them as whole cache lines instead of each thread scattering 41 words.  A culled
     // triangle is in no tile's list, so nobody reads its record and it is not written: only its bin record says so.
     constexpr uint32_t kWords = sizeof(RasterTri) / 4, kNWord = offsetof(RasterTri, n) / 4;
     __shared__ uint32_t stage[256 * kWords];
-    reinterpret_cast<RasterTri*>(stage)[threadIdx.x] = T;
+    RasterTri& T = reinterpret_cast<RasterTri*>(stage)[threadIdx.x];
+    // Triangles a clip plane cuts take the long way (a polygon whose corner count is only known at run time, kept
+    // in private memory).  They are few and scattered over the waves, so they are set aside and worked off
+    // afterwards by the first threads of the workgroup, side by side in as few waves as they fill.
+    __shared__ uint32_t cut_list[256];
+    __shared__ uint32_t cut_count;
+    if (threadIdx.x == 0) cut_count = 0;
     __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = i < n_tris;
+    T.n = 0;
+    const int W = F.W, H = F.H;
+    struct Corners { f3 p0, p1, p2, Nt; f2 t0, t1, t2; };
+    auto corners = [&](uint32_t k) {
+        Corners c;
+        m4 M;
+        memcpy(&M, F.M, 64);
+        c.Nt = mul3(M, f3{N[3 * k], N[3 * k + 1], N[3 * k + 2]});              // rasterizer.cpp:112
+        const int v0 = tri[3 * k], v1 = tri[3 * k + 1], v2 = tri[3 * k + 2];
+        c.p0 = xform(F.M, f3{pos[3 * v0], pos[3 * v0 + 1], pos[3 * v0 + 2]});   // rasterizer.cpp:100
+        c.p1 = xform(F.M, f3{pos[3 * v1], pos[3 * v1 + 1], pos[3 * v1 + 2]});
+        c.p2 = xform(F.M, f3{pos[3 * v2], pos[3 * v2 + 1], pos[3 * v2 + 2]});
+        c.t0 = {uv[2 * v0], uv[2 * v0 + 1]}; c.t1 = {uv[2 * v1], uv[2 * v1 + 1]}; c.t2 = {uv[2 * v2], uv[2 * v2 + 1]};
+        return c;
+    };
+    const int texture = in_range ? mesh_tex[tri_mesh[i]] : -1;       // -1 when the mesh is culled or has no texture
+    if (texture >= 0) {
+        const Corners c = corners(i);
+        if (!(dot(c.p0, c.Nt) > 0)) {                                          // back-face cull, :113
+            bool untouched = true;                  // every corner on the inner side of both planes (a NaN distance is not)
+            for (int plane = 0; plane < 2; ++plane) {
+                const f3 n = {F.frustum[plane][0], F.frustum[plane][1], F.frustum[plane][2]};
+                const float o = F.frustum[plane][3];
+                untouched = untouched && (dot(n, c.p0) - o >= 0) && (dot(n, c.p1) - o >= 0) && (dot(n, c.p2) - o >= 0);
+            }
+            if (untouched) {
+                // what the two clips make of such a triangle: each hands the corners on rotated by one (clip_against)
+                const f3 q[3] = {c.p2, c.p0, c.p1};
+                const f2 tq[3] = {c.t2, c.t0, c.t1};
+                setup_polygon<3>(q, tq, 3, c.Nt, texture, W, H, T);
+            } else {
+                cut_list[atomicAdd(&cut_count, 1u)] = threadIdx.x;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < cut_count) {
+        const uint32_t owner = cut_list[threadIdx.x], k = blockIdx.x * blockDim.x + owner;
+        const Corners c = corners(k);
+        ClipPoly poly;
+        poly.n = 0;
+        poly.add(c.p0, c.t0); poly.add(c.p1, c.t1); poly.add(c.p2, c.t2);
+        for (int plane = 0; plane < 2; ++plane)
+            poly = clip_against(poly, f3{F.frustum[plane][0], F.frustum[plane][1], F.frustum[plane][2]}, F.frustum[plane][3]);
+        if (poly.n >= 3 && poly.n <= 5)
+            setup_polygon<5>(poly.p, poly.t, poly.n, c.Nt, mesh_tex[tri_mesh[k]], W, H, reinterpret_cast<RasterTri*>(stage)[owner]);
+    }
+    __syncthreads();
+    const int n_edges = T.n;
     {
         const uint32_t base = blockIdx.x * 256u, count = min(256u, n_tris - base);
         uint32_t* dst = reinterpret_cast<uint32_t*>(out + base);
@@ -212,7 +260,7 @@ __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* 
             if (stage[(d / kWords) * kWords + kNWord] != 0u) dst[d] = stage[d];
     }
     if (!in_range) return;
-    if (T.n == 0) { bins[i] = make_uint2(0u, 0u); return; }
+    if (n_edges == 0) { bins[i] = make_uint2(0u, 0u); return; }
     // binning, first pass: the triangle's tile range for the fill pass, and the tiles' triangle counts
     const TileRange r = tile_range(T);
     const int cls = depth_class(T, z_near, z_scale);
