@@ -449,8 +449,16 @@ __global__ __launch_bounds__(256) void raster_tile(const RasterTri* setup, const
     const int tile = blockIdx.x, px0 = (tile % tiles_x) << kTileShift, py0 = (tile / tiles_x) << kTileShift;
     const int lane = threadIdx.x & 63;
     const uint32_t begin = tile_start[tile * kDepthClasses], end = min(tile_start[(tile + 1) * kDepthClasses], capacity);
+    uint32_t t_next = 0;
+    {
+        const uint32_t i0 = begin + (threadIdx.x >> 6);
+        if (i0 < end) t_next = pairs[i0];
+    }
     for (uint32_t i = begin + (threadIdx.x >> 6); i < end; i += 4) {
-        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)pairs[i]);
+        // the list entry of the wave's next triangle is requested before this one is drawn: the read of a record
+        // waits for its index, and the index would otherwise be asked for only when the previous triangle is done
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_next);
+        if (i + 4 < end) t_next = pairs[i + 4];
         const RasterTri& T = setup[t];
         const int bx0 = max(T.x0, px0) >> 3, bx1 = min(T.x1, px0 + kTile - 1) >> 3;
         const int by0 = max(T.y0, py0) >> 3, by1 = min(T.y1, py0 + kTile - 1) >> 3;
