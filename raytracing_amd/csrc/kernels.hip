@@ -735,6 +735,7 @@ struct Surf {       // what shading needs from the triangle that was hit
     f3 normal;
     float refl, refr, rindex;
     f4 colorP;
+    uint32_t packed;    // the palette entry colorP was made from (triangles only)
 };
 
 // Triangle::GetColor (raytracer.cpp:362-377): palette level 15, truncating texel address.  The
@@ -755,7 +756,8 @@ __device__ __forceinline__ Surf fetch_surface(const SceneDev& S, const Hit& h) {
     const long long n = (long long)td.y * td.z;
     li = li < 0 ? 0 : (li >= n ? n - 1 : li);
     const uint32_t texel = S.texels[(size_t)td.x + (size_t)li];
-    s.colorP = pixel_to_vec(S.pal[(size_t)tex * (32 * 256) + 15 * 256 + texel]);
+    s.packed = S.pal[(size_t)tex * (32 * 256) + 15 * 256 + texel];
+    s.colorP = pixel_to_vec(s.packed);
     return s;
 }
 
@@ -829,24 +831,37 @@ __device__ __forceinline__ Surf object_surface(const SceneDev& S, int k, f3 hit)
 
 // Direct light of raytracer.cpp:551-570 / 604-623 for the lanes with `shade` set: one shadow
 // ray per light, starting exactly on the surface (no epsilon).  Must be called by all 64 lanes.
-template <bool OBJ, class SC>
+// REMAKE_COLOUR: the surface colour is made again from the packed palette entry after every shadow traversal
+// instead of being kept in four registers across it (the packet kernel is compiled for 64 registers).
+template <bool OBJ, bool REMAKE_COLOUR, class SC>
 __device__ __forceinline__ void direct_light(const SC& sc, const SceneDev& S, bool shade, const Surf& s, f3 hit, f4& finalColor,
                                              int lane, uint32_t& n_shadow, Watch& wd) {
     const float lightStrength = shade ? 1.0f - (s.refr + s.refl) : 0.0f;
     const bool lit = shade && lightStrength > 0.0f;
-    if (lit) finalColor = finalColor + (MRT_AMBIENT * s.colorP) * lightStrength;
+    // the ambient term opens the sum; with REMAKE_COLOUR it is added when the first light's colour is at hand
+    // (same operands, same order), so that nothing of the sum is alive during the first traversal either
+    const bool ambient_later = REMAKE_COLOUR && S.n_lights > 0;
+    if (lit && !ambient_later) finalColor = finalColor + (MRT_AMBIENT * s.colorP) * lightStrength;
     if (!__any(lit)) return;
+    uint32_t packed = s.packed;
     for (int i = 0; i < S.n_lights; ++i) {
-        const float4 lp = S.lights[2 * i], lc = S.lights[2 * i + 1];
+        const float4 lp = S.lights[2 * i];
         const f3 L = lit ? normalize(xyz(lp) - hit) : f3{0.0f, 0.0f, 1.0f};
         bool occluded = occluded_wave(sc, S.n_tris, S.coords_ok != 0, hit, L, lit, not_grazing(L, s.normal), lane, wd);
         if constexpr (OBJ) { if (lit && !occluded) occluded = objects_occlude(S, hit, L); }
+        const float4 lc = S.lights[2 * i + 1];         // read after the traversal: nothing to keep alive across it
+        f4 colorP = s.colorP;
+        if constexpr (REMAKE_COLOUR) {
+            asm volatile("" : "+v"(packed));        // (keeps the compiler from holding on to the first conversion)
+            colorP = pixel_to_vec(packed);
+            if (lit && i == 0) finalColor = finalColor + (MRT_AMBIENT * colorP) * lightStrength;
+        }
         if (lit) {
             ++n_shadow;
             if (!occluded) {
                 float d = dot(s.normal, L);
                 if (d < 0.0f) d = 0.0f;
-                finalColor = finalColor + ((d * f4{lc.x, lc.y, lc.z, lc.w}) * s.colorP) * lightStrength;
+                finalColor = finalColor + ((d * f4{lc.x, lc.y, lc.z, lc.w}) * colorP) * lightStrength;
             }
         }
     }
@@ -902,7 +917,7 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
         if (tracing && first) { primary = h; first = false; }
         const bool shade = tracing && isHit;
         Surf s;
-        s.normal = {0, 0, 1}; s.refl = 0; s.refr = 0; s.rindex = 1; s.colorP = {0, 0, 0, 0};
+        s.normal = {0, 0, 1}; s.refl = 0; s.refr = 0; s.rindex = 1; s.colorP = {0, 0, 0, 0}; s.packed = 0;
         f3 hit = O;
         if (shade) {
             hit = O + D * t;
@@ -910,7 +925,7 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
         }
         f4 finalColor = {0, 0, 0, 0};
         MRT_PHASE_BEGIN(wd);
-        direct_light<OBJ>(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
+        direct_light<OBJ, false>(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
         MRT_PHASE_END(wd, 17);
         if (!tracing) continue;
         tracing = false;
@@ -1004,8 +1019,8 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
         const int blk = lr / F.part_block;
         ty = ((blk * F.n_parts + F.part) * F.part_block + (lr - blk * F.part_block)) * F.grid_g + sub;
     }
-    const int x = tx * 8 + (lane & 7), y = ty * 8 + (lane >> 3);
-    const int y_store = (F.compact ? ltr : ty) * 8 + (lane >> 3);    // row of the traced image as laid out in fb / hit_ids
+    int x = tx * 8 + (lane & 7);
+    const int y = ty * 8 + (lane >> 3);
 
     const f3 p0 = {F.p0[0], F.p0[1], F.p0[2]}, d10 = {F.d10[0], F.d10[1], F.d10[2]}, d20 = {F.d20[0], F.d20[1], F.d20[2]};
     const f3 O = {F.cam[0], F.cam[1], F.cam[2]};
@@ -1026,20 +1041,28 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
         if constexpr (OBJ) trace_objects(S, O, D, t, h);
         const bool shade = h.tri != -1;
         Surf s;
-        s.normal = {0, 0, 1}; s.refl = 0; s.refr = 0; s.rindex = 1; s.colorP = {0, 0, 0, 0};
+        s.normal = {0, 0, 1}; s.refl = 0; s.refr = 0; s.rindex = 1; s.colorP = {0, 0, 0, 0}; s.packed = 0;
         f3 hit = O;
         if (shade) {
             hit = O + D * t;
             if (!OBJ || h.tri >= 0) s = fetch_surface(S, h); else s = object_surface(S, -2 - h.tri, hit);
         }
         f4 finalColor = {0, 0, 0, 0};
-        direct_light<OBJ>(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
+        direct_light<OBJ, !OBJ>(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
         color = shade ? clamp01(finalColor) : MRT_BACKGROUND;
     } else {
         color = shade_recursive<OBJ>(sc, S, O, D, stack, lane, h, n_shadow, n_secondary, wd);
     }
     const uint32_t px = vec_to_pixel(color);
 
+    // where the pixel goes: made again from the tile and the lane rather than carried through the traversals (in the
+    // 64-register packet kernel the carried value was spilled to private memory, one store per lane and tile)
+    {
+        int lane_again = lane;
+        asm volatile("" : "+v"(lane_again));
+        x = tx * 8 + (lane_again & 7);
+    }
+    const int y_store = (F.compact ? ltr : ty) * 8 + (lane >> 3);    // row of the traced image as laid out in fb / hit_ids
     if (F.hit_ids) F.hit_ids[(size_t)y_store * F.width + x] = h.tri;
     const int g = F.grid_g;
     if (g == 1) {
