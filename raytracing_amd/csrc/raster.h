@@ -51,6 +51,7 @@ struct RasterState {
     uint32_t* d_total = nullptr;     // [0] (tile, triangle) pairs this frame, [1] length of the big-triangle list
     uint32_t* d_tile_count = nullptr; // per (32x32 tile, depth class): triangle count, then fill cursor
     uint32_t* d_tile_start = nullptr; // per (tile, depth class) (+1): start of its list segment in d_pairs
+    uint32_t* d_scan_sums = nullptr;  // sums of chunks of d_tile_count (the scan's first pass)
     uint32_t n_tile_slots = 0;
     uint32_t* d_pairs = nullptr;     // triangle indices, grouped by tile
     size_t pair_capacity = 0;

@@ -5,7 +5,7 @@
 //                     constants and the screen-space plane equations of 1/z, u/z and v/z
 //                     (rasterizer.cpp:100-141); it also counts the triangle into the 32x32-pixel
 //                     screen tiles its pixel bounding box overlaps.
-//   raster_tile_scan, raster_fill_small, raster_bin_big
+//   raster_tile_sums, raster_tile_scan, raster_fill_small, raster_bin_big
 //                     exclusive scan of the tile counts, then the tiles' triangle lists are filled (a
 //                     triangle overlapping more than 16 tiles is counted and filled by a whole wave,
 //                     lanes striding over its tiles).
@@ -374,59 +374,79 @@ __global__ __launch_bounds__(256) void raster_bin_big(const uint2* bins, int til
                           capacity);
     }
 }
-// exclusive scan of the list-segment counts by one workgroup, 32,768 consecutive entries at a time (32 per
-// thread, all loads of a round in flight together: the counts were written by atomics and come from memory);
-// total[0] receives the number of (tile, triangle) pairs.  count and start are 16-byte aligned.  The counts are
-// cleared as they are read: the fill pass uses the same array as its cursors.
-__global__ __launch_bounds__(1024) void raster_tile_scan(uint32_t* tile_count, uint32_t* tile_start, uint32_t n, uint32_t* total) {
-    constexpr int kPer = 32;
-    __shared__ uint32_t wave_sum[16];
+// Exclusive scan of the list-segment counts in two small launches: raster_tile_sums adds up chunks of kScanChunk
+// consecutive counts (one workgroup each), raster_tile_scan lets every workgroup add the sums of the chunks before
+// its own and scan its chunk.  The counts are cleared on the way: they become the fill cursors of the second
+// binning pass.  tile_start[n] and total[0] receive the grand total.  (One workgroup scanning everything took
+// 28 us for the 65,280 segments of a 4K frame.)
+constexpr uint32_t kScanChunk = 2048;        // 256 threads x 8 counts
+__global__ __launch_bounds__(256) void raster_tile_sums(const uint32_t* tile_count, uint32_t n, uint32_t* chunk_sum) {
+    __shared__ uint32_t wave_sum[4];
+    const uint32_t first = blockIdx.x * kScanChunk + 8u * threadIdx.x;
+    uint32_t mine = 0;
+    if (first + 8u <= n) {
+        const uint4 a = *reinterpret_cast<const uint4*>(tile_count + first), b = *reinterpret_cast<const uint4*>(tile_count + first + 4);
+        mine = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+    } else {
+        for (uint32_t k = first; k < n; ++k) mine += tile_count[k];
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += (uint32_t)__shfl_xor((int)mine, o, 64);
+    if ((threadIdx.x & 63u) == 0u) wave_sum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+}
+__global__ __launch_bounds__(256) void raster_tile_scan(uint32_t* tile_count, uint32_t* tile_start, uint32_t n, const uint32_t* chunk_sum,
+                                                         uint32_t* total) {
+    __shared__ uint32_t wave_sum[4];
+    __shared__ uint32_t before_chunk;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < n; base += 1024u * kPer) {
-        const uint32_t first = base + kPer * t;
-        uint32_t v[kPer], mine = 0;
-        if (first + kPer <= n) {
-#pragma unroll
-            for (int k = 0; k < kPer; k += 4) {
-                const uint4 q = *reinterpret_cast<const uint4*>(tile_count + first + k);
-                v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
-                *reinterpret_cast<uint4*>(tile_count + first + k) = make_uint4(0u, 0u, 0u, 0u);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < kPer; ++k) {
-                v[k] = first + k < n ? tile_count[first + k] : 0u;
-                if (first + k < n) tile_count[first + k] = 0u;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) mine += v[k];
-        uint32_t incl = mine;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
-            if (lane >= (uint32_t)o) incl += up;
-        }
-        if (lane == 63u) wave_sum[wave] = incl;
+    {   // the chunks before this one
+        uint32_t s = 0;
+        for (uint32_t k = t; k < blockIdx.x; k += 256u) s += chunk_sum[k];
+        for (int o = 32; o > 0; o >>= 1) s += (uint32_t)__shfl_xor((int)s, o, 64);
+        if (lane == 0u) wave_sum[wave] = s;
         __syncthreads();
-        uint32_t before = 0, all = 0;
-        for (uint32_t w = 0; w < 16u; ++w) { const uint32_t x = wave_sum[w]; all += x; if (w < wave) before += x; }
-        uint32_t run = carry + before + incl - mine;
-        if (first + kPer <= n) {
-#pragma unroll
-            for (int k = 0; k < kPer; k += 4) {
-                uint4 q;
-                q.x = run; run += v[k]; q.y = run; run += v[k + 1]; q.z = run; run += v[k + 2]; q.w = run; run += v[k + 3];
-                *reinterpret_cast<uint4*>(tile_start + first + k) = q;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < kPer; ++k) { if (first + k < n) tile_start[first + k] = run; run += v[k]; }
-        }
-        carry += all;
+        if (t == 0) before_chunk = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
         __syncthreads();
     }
-    if (t == 0) { tile_start[n] = carry; total[0] = carry; }
+    const uint32_t first = blockIdx.x * kScanChunk + 8u * t;
+    uint32_t v[8], mine = 0;
+    const bool whole = first + 8u <= n;
+    if (whole) {
+        const uint4 a = *reinterpret_cast<const uint4*>(tile_count + first), b = *reinterpret_cast<const uint4*>(tile_count + first + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        *reinterpret_cast<uint4*>(tile_count + first) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(tile_count + first + 4) = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = first + k < n ? tile_count[first + k] : 0u;
+            if (first + k < n) tile_count[first + k] = 0u;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mine += v[k];
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= (uint32_t)o) incl += up;
+    }
+    if (lane == 63u) wave_sum[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (uint32_t w = 0; w < 4u; ++w) { const uint32_t x = wave_sum[w]; all += x; if (w < wave) before += x; }
+    uint32_t run = before_chunk + before + incl - mine;
+    if (whole) {
+        uint4 a, b;
+        a.x = run; run += v[0]; a.y = run; run += v[1]; a.z = run; run += v[2]; a.w = run; run += v[3];
+        b.x = run; run += v[4]; b.y = run; run += v[5]; b.z = run; run += v[6]; b.w = run; run += v[7];
+        *reinterpret_cast<uint4*>(tile_start + first) = a;
+        *reinterpret_cast<uint4*>(tile_start + first + 4) = b;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { if (first + k < n) tile_start[first + k] = run; run += v[k]; }
+    }
+    if (blockIdx.x == gridDim.x - 1 && t == 0) { tile_start[n] = before_chunk + all; total[0] = before_chunk + all; }
 }
 
 __global__ __launch_bounds__(256) void raster_tile(const RasterTri* setup, const uint32_t* tile_start, const uint32_t* pairs, int tiles_x,
@@ -518,7 +538,7 @@ __global__ __launch_bounds__(256) void raster_tile(const RasterTri* setup, const
 
 void raster_release(RasterState& R) {
     for (void* p : {(void*)R.d_pos, (void*)R.d_uv, (void*)R.d_N, (void*)R.d_tri, (void*)R.d_tri_mesh, (void*)R.d_mesh_tex, (void*)R.d_setup, (void*)R.d_bins,
-                    (void*)R.d_pairs, (void*)R.d_chunk_base, (void*)R.d_total, (void*)R.d_tile_count, (void*)R.d_tile_start,
+                    (void*)R.d_pairs, (void*)R.d_chunk_base, (void*)R.d_total, (void*)R.d_tile_count, (void*)R.d_tile_start, (void*)R.d_scan_sums,
                     (void*)R.d_fb, (void*)R.d_z, (void*)R.d_ids})
         if (p) (void)hipFree(p);
     if (R.h_stage) (void)hipHostFree(R.h_stage);
@@ -648,6 +668,9 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
         R.d_tile_count = nullptr; R.d_tile_start = nullptr; R.n_tile_slots = 0;
         RASTER_HIP(hipMalloc((void**)&R.d_tile_count, (size_t)(n_slots + 1) * 4));
         RASTER_HIP(hipMalloc((void**)&R.d_tile_start, (size_t)(n_slots + 1) * 4));
+        if (R.d_scan_sums) (void)hipFree(R.d_scan_sums);
+        R.d_scan_sums = nullptr;
+        RASTER_HIP(hipMalloc((void**)&R.d_scan_sums, (size_t)((n_slots + kScanChunk - 1) / kScanChunk + 1) * 4));
         R.n_tile_slots = n_slots + 1;
     }
     RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_slots + 1) * 4, stream));
@@ -659,7 +682,9 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
                            R.d_bins, tiles_x, R.d_tile_count, R.d_chunk_base, R.d_total + 1, z_near, z_scale);
         hipLaunchKernelGGL((raster_bin_big<false>), dim3(kBigWaves / 4), b256, 0, stream, R.d_bins, tiles_x, R.d_tile_count, R.d_tile_start,
                            (uint32_t*)nullptr, R.d_chunk_base, R.d_total + 1, 0u);
-        hipLaunchKernelGGL(raster_tile_scan, dim3(1), dim3(1024), 0, stream, R.d_tile_count, R.d_tile_start, n_slots, R.d_total);
+        const uint32_t n_chunks = (n_slots + kScanChunk - 1) / kScanChunk;
+        hipLaunchKernelGGL(raster_tile_sums, dim3(n_chunks), b256, 0, stream, R.d_tile_count, n_slots, R.d_scan_sums);
+        hipLaunchKernelGGL(raster_tile_scan, dim3(n_chunks), b256, 0, stream, R.d_tile_count, R.d_tile_start, n_slots, R.d_scan_sums, R.d_total);
     }
     // A frame in page-locked memory (mrt_host_alloc) is written by the kernel itself, covered pixels only; any
     // other frame comes back through page-locked staging and its covered pixels are merged in on the host
