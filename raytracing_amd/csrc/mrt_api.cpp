@@ -63,6 +63,11 @@ struct DevBuf {
         return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    // a buffer dies with whatever owns it (mrt_destroy deletes the context with its device current)
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
 };
 }  // namespace
 
@@ -391,6 +396,7 @@ void mrt_destroy(mrt_ctx* c) {
     c->d_rayO.release(); c->d_rayD.release(); c->d_rayR.release(); c->d_rayT.release(); c->d_rayU.release(); c->d_rayV.release();
     c->d_rayTri.release(); c->d_rayFlag.release();
     c->d_nodes.release(); c->d_triA.release(); c->d_triB.release(); c->d_triC.release(); c->d_attr.release(); c->d_lights.release();
+    c->d_triG.release(); c->d_triM.release(); c->d_eye_nodes.release(); c->d_eye_tri.release(); c->d_eye_g.release();
     c->d_tex.release(); c->d_texels.release(); c->d_pal.release(); c->d_objects.release();
     c->d_fb.release(); c->d_ids.release(); c->d_counters.release();
     c->d_tile_cost.release(); c->d_tile_packed.release(); c->d_tile_order.release();
