@@ -527,6 +527,157 @@ __global__ __launch_bounds__(256) void raster_tile(const RasterTri* setup, const
     }
 }
 
+// word offsets of a RasterTri's fields (the record as 41 consecutive words)
+constexpr int kRecWords = (int)(sizeof(RasterTri) / 4);
+constexpr int kRecEx = (int)(offsetof(RasterTri, ex) / 4), kRecEy = (int)(offsetof(RasterTri, ey) / 4), kRecDx = (int)(offsetof(RasterTri, dx) / 4);
+constexpr int kRecIy0 = (int)(offsetof(RasterTri, iy0) / 4), kRecIy1 = (int)(offsetof(RasterTri, iy1) / 4), kRecN = (int)(offsetof(RasterTri, n) / 4);
+constexpr int kRecX0 = (int)(offsetof(RasterTri, x0) / 4), kRecZ = (int)(offsetof(RasterTri, zA) / 4);
+static_assert(kRecWords <= 64, "a triangle record must fit one word per lane");
+
+// Maximum of an unsigned value over the 64 lanes of a wave, returned wave-uniform: four DPP steps inside the rows of
+// 16 lanes (swap neighbours, swap pairs, mirror the half row, mirror the row), then the four rows are combined from
+// scalar reads.  All 64 lanes must be active.
+__device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
+    v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));      // quad_perm [1,0,3,2]
+    v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));      // quad_perm [2,3,0,1]
+    v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true));     // row_half_mirror
+    v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true));     // row_mirror
+    const unsigned int a = (unsigned int)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned int)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned int c = (unsigned int)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned int)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+
+// The tile kernel with the depth cells in registers.  A wave owns one 32x8 strip of the tile (wave w: rows 8w .. 8w+7),
+// a lane one pixel in each of the strip's four 8x8 blocks (the same row, columns 8 apart), and every wave walks the
+// tile's WHOLE list: a cell has one owner, so the depth test is a compare and a select on the owner's registers (no
+// atomics, no LDS), and the result is the same minimum over {1/z, triangle index} per pixel.  A lane's four pixels
+// share their row, so the row's extent in a triangle (covers()) is worked out once per triangle.  The bounds work as
+// in raster_tile (the largest key of a block's cells, of the strip's cells), kept wave-uniform in scalar registers.
+// The list is taken 64 entries at a time, one per lane, to find the triangles that reach into the strip and can still
+// win a pixel; those are then drawn one after the other in list order.  A triangle's record is read by ONE load, lane
+// i taking word i, and its fields are picked out of that register as scalars; the records of the next two
+// candidates are on their way while the current one is drawn (vector loads complete in order, so each is waited for
+// on its own).
+template <int NB>      // 8x8 blocks per wave: 4 (a 32x8 strip, 4 waves per tile), 2 (16x8, 8 waves) or 1 (8x8, 16 waves)
+__global__ __launch_bounds__(1024 / NB) void raster_tile_owned(const RasterTri* __restrict__ setup, const uint32_t* __restrict__ tile_start,
+                                                         const uint32_t* __restrict__ pairs, int tiles_x,
+                                                         RasterTextures tx, uint32_t* fb, int fb_pitch, int keep_uncovered, float* zbuf, int32_t* ids,
+                                                         int W, int H, uint32_t capacity) {
+    const int tile = blockIdx.x, px0 = (tile % tiles_x) << kTileShift, py0 = (tile / tiles_x) << kTileShift;
+    const int lane = threadIdx.x & 63, wave = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr int kPerRow = 4 / NB;                                                  // waves side by side in a row of blocks
+    const int sy0 = py0 + ((wave / kPerRow) << 3);                                   // the wave's first row
+    const int sx0 = px0 + (wave % kPerRow) * (NB << 3);                              // and its first column
+    const int lx = lane & 7, y = sy0 + (lane >> 3);                                  // this lane's row
+    const float yf = (float)y;
+    const unsigned long long empty = ((unsigned long long)orderable(0.0f) << 32) | 0xffffffffull;   // the cleared z-buffer, no triangle
+    unsigned long long k0 = empty, k1 = empty, k2 = empty, k3 = empty;              // this lane's cells at columns lx, lx + 8, lx + 16, lx + 24
+    unsigned int m0 = orderable(0.0f), m1 = m0, m2 = m0, m3 = m0, strip_max = m0;   // wave-uniform bounds
+    const uint32_t begin = tile_start[tile * kDepthClasses], end = min(tile_start[(tile + 1) * kDepthClasses], capacity);
+    const float ya = (float)sy0, yb = (float)(sy0 + 7);
+    // lane 4b + c (b < NB) looks after corner c of block b in the bound test of every triangle
+    const int corner_block = (lane >> 2) < NB ? (sx0 >> 3) + (lane >> 2) : -1;          // -1: this lane's vote never counts
+    const float corner_x = (float)((corner_block << 3) + ((lane & 1) ? 7 : 0)), corner_y = (lane & 2) ? yb : ya;
+    unsigned int bound_v = orderable(0.0f);                                              // the bound of this lane's block
+    for (uint32_t base = begin; base < end; base += 64) {
+        uint32_t t_lane = 0;
+        bool cand = false;
+        if (base + lane < end) {
+            t_lane = pairs[base + lane];
+            const RasterTri& R = setup[t_lane];
+            if (R.y0 <= sy0 + 7 && R.y1 >= sy0 && R.x0 <= sx0 + 8 * NB - 1 && R.x1 >= sx0) {
+                const int x0 = max(R.x0, sx0), x1 = min(R.x1, sx0 + 8 * NB - 1);
+                const float xa = (float)(x0 & ~7), xb = (float)(x1 | 7);
+                const float c0 = R.zA * xa + R.zB * ya + R.zC, c1 = R.zA * xb + R.zB * ya + R.zC;
+                const float c2 = R.zA * xa + R.zB * yb + R.zC, c3 = R.zA * xb + R.zB * yb + R.zC;
+                const float zmin = fminf(fminf(c0, c1), fminf(c2, c3));
+                cand = !(zmin == zmin && orderable(zmin) > strip_max);
+            }
+        }
+        unsigned long long todo = __ballot(cand);
+        auto fetch = [&](unsigned long long from) -> uint32_t {       // the record of the first candidate in `from`
+            if (from == 0) return 0u;
+            const uint32_t tn = (uint32_t)__builtin_amdgcn_readlane((int)t_lane, __ffsll((long long)from) - 1);
+            return lane < kRecWords ? reinterpret_cast<const uint32_t*>(setup + tn)[lane] : 0u;
+        };
+        uint32_t rec_a = fetch(todo), rec_b = fetch(todo & (todo - 1ull));
+        while (todo) {
+            const int j = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)t_lane, j);
+            const uint32_t rec = rec_a;
+            rec_a = rec_b;
+            rec_b = fetch(todo & (todo - 1ull));
+            auto wi = [&](int w) { return __builtin_amdgcn_readlane((int)rec, w); };
+            auto wf = [&](int w) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)rec, w)); };
+            const int tx0 = wi(kRecX0), tx1 = wi(kRecX0 + 1), ty0 = wi(kRecX0 + 2), ty1 = wi(kRecX0 + 3);
+            const float zA = wf(kRecZ), zB = wf(kRecZ + 1), zC = wf(kRecZ + 2);
+            const int bx0 = max(tx0, sx0) >> 3, bx1 = min(tx1, sx0 + 8 * NB - 1) >> 3;
+            const int n_edges = wi(kRecN);
+            // covers() for this lane's row: columns ix0 .. ix1 are plotted (none when ix0 > ix1)
+            int ix0 = 1, ix1 = 0;
+            if (y >= ty0 && y <= ty1) {
+                float xl = (float)(W - 1), xr = 0.0f;
+                bool any = false;
+#pragma unroll
+                for (int e = 0; e < 5; ++e) {
+                    if (e >= n_edges) break;
+                    if (y < wi(kRecIy0 + e) || y > wi(kRecIy1 + e)) continue;
+                    const float xe = wf(kRecEx + e) + wf(kRecDx + e) * (yf - wf(kRecEy + e));
+                    if (xe < xl) xl = xe;
+                    if (xe > xr) xr = xe;
+                    any = true;
+                }
+                if (any) { ix0 = max((int)xl + 1, tx0); ix1 = min(min(W - 2, (int)xr), tx1); }
+            }
+            const float zrow = zB * yf;
+            // Which of the wave's blocks can the triangle still win a pixel in?  Lane 4b + c evaluates 1/z at corner c of
+            // block b (the arithmetic of the per-pixel test, as in raster_tile), two swaps inside the groups of four
+            // lanes take the minimum over a block's corners in the order min(min(c0, c1), min(c2, c3)), and one vote
+            // collects the blocks that the triangle reaches and whose bound it is not above.
+            unsigned int blocks;
+            {
+                const float zc = zA * corner_x + zB * corner_y + zC;
+                float zq = fminf(zc, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zc), 0xB1, 0xf, 0xf, true)));
+                zq = fminf(zq, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zq), 0x4E, 0xf, 0xf, true)));
+                const bool open = corner_block >= bx0 && corner_block <= bx1 && !(zq == zq && orderable(zq) > bound_v);   // a NaN decides nothing
+                blocks = (unsigned int)__ballot(open) & 0x1111u;
+            }
+            bool lowered = false;
+            auto block = [&](int bi, unsigned long long& k, unsigned int& bm) {
+                if (!((blocks >> (4 * bi)) & 1u)) return;
+                const int x = sx0 + (bi << 3) + lx;
+                bool won = false;
+                if (x >= ix0 && x <= ix1) {
+                    const float z0 = zA * (float)x + zrow + zC;
+                    if (z0 < 0.0f) {                    // the z-buffer is cleared to 0 and the test is "z0 >= zbuf: skip" (:55, :177)
+                        const unsigned long long key = ((unsigned long long)orderable(z0) << 32) | t;
+                        won = key < k;
+                        k = won ? key : k;
+                    }
+                }
+                if (__any(won)) { bm = wave_max_u32((unsigned int)(k >> 32)); lowered = true; }
+            };
+            block(0, k0, m0);
+            if constexpr (NB > 1) block(1, k1, m1);
+            if constexpr (NB > 2) { block(2, k2, m2); block(3, k3, m3); }
+            if (lowered) {
+                const int cb = (lane >> 2) & 3;
+                bound_v = cb == 0 ? m0 : cb == 1 ? m1 : cb == 2 ? m2 : m3;
+            }
+            if (lowered) strip_max = NB == 1 ? m0 : NB == 2 ? max(m0, m1) : max(max(m0, m1), max(m2, m3));
+        }
+    }
+    auto resolve = [&](int b, unsigned long long k) {
+        const int x = sx0 + (b << 3) + lx;
+        if (x < W && y < H)
+            resolve_pixel(setup, k, tx, x, y, (size_t)y * W + x, fb, (size_t)y * fb_pitch + x, keep_uncovered != 0, zbuf, ids);
+    };
+    resolve(0, k0);
+    if constexpr (NB > 1) resolve(1, k1);
+    if constexpr (NB > 2) { resolve(2, k2); resolve(3, k3); }
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -740,7 +891,10 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
             hipLaunchKernelGGL((raster_bin_big<true>), dim3(kBigWaves / 4), b256, 0, stream, R.d_bins, tiles_x, R.d_tile_count, R.d_tile_start,
                                R.d_pairs, R.d_chunk_base, R.d_total + 1, capacity);
         }
-        hipLaunchKernelGGL(raster_tile, dim3(n_tiles), dim3(256), 0, stream, R.d_setup, R.d_tile_start, R.d_pairs, tiles_x, tx,
+#ifndef MRT_RASTER_NB
+#define MRT_RASTER_NB 4
+#endif
+        hipLaunchKernelGGL(raster_tile_owned<MRT_RASTER_NB>, dim3(n_tiles), dim3(1024 / MRT_RASTER_NB), 0, stream, R.d_setup, R.d_tile_start, R.d_pairs, tiles_x, tx,
                            fb_direct ? fb_direct : R.d_fb, fb_direct ? pitch_px : W, fb_direct ? 1 : 0,
                            zbuf ? (device_out ? zbuf : R.d_z) : nullptr, tri_ids ? (device_out ? tri_ids : R.d_ids) : nullptr, W, H, capacity);
         RASTER_HIP(hipGetLastError());
