@@ -9,14 +9,14 @@
 //                     exclusive scan of the tile counts, then the tiles' triangle lists are filled (a
 //                     triangle overlapping more than 16 tiles is counted and filled by a whole wave,
 //                     lanes striding over its tiles).
-//   raster_tile       one workgroup per tile, depth cells of the tile in LDS.  Each wave takes every
-//                     fourth triangle of the tile's list; one lane per pixel of an 8x8 block.  A
-//                     pixel is covered exactly when the reference's scan conversion would plot it
-//                     (rows y0 < y <= y1 of the spanning edges, columns xl < x <= xr of the row's
-//                     extent, rasterizer.cpp:143-182), and the depth test is a 64-bit LDS atomicMin
-//                     on {orderable 1/z, triangle index}: the reference draws triangles in order and
-//                     skips a pixel when the new 1/z is >= the stored one, i.e. the smallest 1/z
-//                     wins and, among equals, the first triangle drawn.  The workgroup then resolves
+//   raster_tile       one workgroup per tile, depth cells of the tile in registers.  A wave owns a 32x8 strip
+//                     of the tile and walks the tile's whole list; a lane owns one pixel in each of the
+//                     strip's four 8x8 blocks.  A pixel is covered exactly when the reference's scan
+//                     conversion would plot it (rows y0 < y <= y1 of the spanning edges, columns
+//                     xl < x <= xr of the row's extent, rasterizer.cpp:143-182), and the depth test keeps
+//                     the minimum of {orderable 1/z, triangle index}: the reference draws triangles in
+//                     order and skips a pixel when the new 1/z is >= the stored one, i.e. the smallest
+//                     1/z wins and, among equals, the first triangle drawn.  Every lane then resolves
 //                     its own pixels: texel fetch and palette lookup of the winner
 //                     (rasterizer.cpp:178-180), optional 1/z and triangle-id planes.
 //
@@ -270,28 +270,6 @@ __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* 
         for (int k = 0; k < r.tw; ++k) atomicAdd(&tile_count[((r.ty0 + j) * tiles_x + r.tx0 + k) * kDepthClasses + cls], 1u);
 }
 
-// Is pixel (x, y) plotted by the reference's scan conversion of this polygon?  The row extent of
-// rasterizer.cpp:143-170: every edge contributes to the rows it spans; the row's extent is
-// [min x, max x] over those edges; columns (int)xl+1 .. min(W-2, (int)xr).
-__device__ __forceinline__ bool covers(const RasterTri& T, int x, int y, int W) {
-    float xl = (float)(W - 1), xr = 0.0f;             // the outline tables' idle values, :28, :164
-    bool any = false;
-    // unrolled over the five possible edges: with constant indices the triangle record, which is the
-    // same for the whole wave, stays in scalar registers instead of being re-read per lane and edge
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        if (j >= T.n) break;
-        if (y < T.iy0[j] || y > T.iy1[j]) continue;
-        const float xe = T.ex[j] + T.dx[j] * ((float)y - T.ey[j]);
-        if (xe < xl) xl = xe;
-        if (xe > xr) xr = xe;
-        any = true;
-    }
-    if (!any) return false;
-    const int ix0 = (int)xl + 1, ix1 = min(W - 2, (int)xr);
-    return x >= ix0 && x <= ix1;
-}
-
 // texel fetch and palette lookup of a pixel's depth winner (rasterizer.cpp:178-180)
 __device__ __forceinline__ void resolve_pixel(const RasterTri* setup, unsigned long long key, const RasterTextures& tx, int x, int y,
                                               size_t p, uint32_t* fb, size_t pf, bool keep_uncovered, float* zbuf, int32_t* ids) {
@@ -322,8 +300,8 @@ __device__ __forceinline__ void resolve_pixel(const RasterTri* setup, unsigned l
 
 // ---------------------------------------------------------------------------------------
 // Tiled path: triangles are binned to 32x32-pixel screen tiles, and one workgroup per tile keeps
-// the tile's depth cells in LDS, so the depth test is an LDS atomic instead of a device-scope
-// atomic in memory, and resolves its own pixels.  The result is the same minimum over
+// the tile's depth cells on chip (in the registers of the lanes that own them), so the depth test
+// needs no device-scope atomic in memory, and resolves its own pixels.  The result is the minimum over
 // {1/z, triangle index} per pixel, whatever the order in which a tile meets its triangles.
 // ---------------------------------------------------------------------------------------
 
@@ -449,84 +427,6 @@ __global__ __launch_bounds__(256) void raster_tile_scan(uint32_t* tile_count, ui
     if (blockIdx.x == gridDim.x - 1 && t == 0) { tile_start[n] = before_chunk + all; total[0] = before_chunk + all; }
 }
 
-__global__ __launch_bounds__(256) void raster_tile(const RasterTri* setup, const uint32_t* tile_start, const uint32_t* pairs, int tiles_x,
-                                                   RasterTextures tx, uint32_t* fb, int fb_pitch, int keep_uncovered, float* zbuf, int32_t* ids,
-                                                   int W, int H, uint32_t capacity) {
-    __shared__ unsigned long long cell[kTile * kTile];
-    // Per 8x8 block of the tile: an upper bound of the depth keys its 64 cells hold.  Cells only ever
-    // decrease, so a maximum read at any time stays an upper bound; a triangle whose smallest 1/z over
-    // the block is above it cannot win any of the block's pixels (equal 1/z is not skipped: the lower
-    // triangle index wins ties) and the block is not tested at all.  1/z is evaluated as
-    // (zA*x + zB*y) + zC with every operation rounded, which is monotone in x and in y, so its
-    // minimum over the block is taken at a corner, in exactly the arithmetic of the per-pixel test.
-    __shared__ unsigned int block_max[(kTile / 8) * (kTile / 8)];
-    __shared__ unsigned int tile_max;                 // the same bound over the whole tile: one test skips a far triangle altogether
-    const unsigned long long empty = ((unsigned long long)orderable(0.0f) << 32) | 0xffffffffull;   // the cleared z-buffer, no triangle
-    for (int p = threadIdx.x; p < kTile * kTile; p += 256) cell[p] = empty;
-    if (threadIdx.x < (kTile / 8) * (kTile / 8)) block_max[threadIdx.x] = orderable(0.0f);
-    if (threadIdx.x == 0) tile_max = orderable(0.0f);
-    __syncthreads();
-    const int tile = blockIdx.x, px0 = (tile % tiles_x) << kTileShift, py0 = (tile / tiles_x) << kTileShift;
-    const int lane = threadIdx.x & 63;
-    const uint32_t begin = tile_start[tile * kDepthClasses], end = min(tile_start[(tile + 1) * kDepthClasses], capacity);
-    uint32_t t_next = 0;
-    {
-        const uint32_t i0 = begin + (threadIdx.x >> 6);
-        if (i0 < end) t_next = pairs[i0];
-    }
-    for (uint32_t i = begin + (threadIdx.x >> 6); i < end; i += 4) {
-        // the list entry of the wave's next triangle is requested before this one is drawn: the read of a record
-        // waits for its index, and the index would otherwise be asked for only when the previous triangle is done
-        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_next);
-        if (i + 4 < end) t_next = pairs[i + 4];
-        const RasterTri& T = setup[t];
-        const int bx0 = max(T.x0, px0) >> 3, bx1 = min(T.x1, px0 + kTile - 1) >> 3;
-        const int by0 = max(T.y0, py0) >> 3, by1 = min(T.y1, py0 + kTile - 1) >> 3;
-        {
-            const float xa = (float)(bx0 << 3), xb = (float)((bx1 << 3) + 7), ya = (float)(by0 << 3), yb = (float)((by1 << 3) + 7);
-            const float c0 = T.zA * xa + T.zB * ya + T.zC, c1 = T.zA * xb + T.zB * ya + T.zC;
-            const float c2 = T.zA * xa + T.zB * yb + T.zC, c3 = T.zA * xb + T.zB * yb + T.zC;
-            const float zmin = fminf(fminf(c0, c1), fminf(c2, c3));
-            if (zmin == zmin && orderable(zmin) > tile_max) continue;
-        }
-        for (int by = by0; by <= by1; ++by)
-            for (int bx = bx0; bx <= bx1; ++bx) {
-                const int blk = (by - (py0 >> 3)) * (kTile / 8) + (bx - (px0 >> 3));
-                {
-                    const float xa = (float)(bx << 3), xb = (float)((bx << 3) + 7), ya = (float)(by << 3), yb = (float)((by << 3) + 7);
-                    const float c0 = T.zA * xa + T.zB * ya + T.zC, c1 = T.zA * xb + T.zB * ya + T.zC;
-                    const float c2 = T.zA * xa + T.zB * yb + T.zC, c3 = T.zA * xb + T.zB * yb + T.zC;
-                    const float zmin = fminf(fminf(c0, c1), fminf(c2, c3));
-                    if (zmin == zmin && orderable(zmin) > block_max[blk]) continue;      // wave-uniform; a NaN decides nothing
-                }
-                const int x = (bx << 3) + (lane & 7), y = (by << 3) + (lane >> 3);
-                bool won = false;
-                if (!(x < T.x0 || x > T.x1 || y < T.y0 || y > T.y1) && covers(T, x, y, W)) {
-                    const float z0 = T.zA * (float)x + T.zB * (float)y + T.zC;
-                    if (z0 < 0.0f) {                    // the z-buffer is cleared to 0 and the test is "z0 >= zbuf: skip" (:55, :177)
-                        const unsigned long long key = ((unsigned long long)orderable(z0) << 32) | t;
-                        won = key < atomicMin(&cell[(y - py0) * kTile + (x - px0)], key);
-                    }
-                }
-                if (__any(won)) {
-                    // some cell of the block went down: a new bound from what the cells hold now
-                    unsigned int m = (unsigned int)(cell[(((by << 3) - py0) + (lane >> 3)) * kTile + ((bx << 3) - px0) + (lane & 7)] >> 32);
-                    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o, 64));
-                    if (lane == 0) atomicMin(&block_max[blk], m);
-                    unsigned int tm = block_max[lane & 15];          // lane 0's update included: LDS operations of a wave complete in order
-                    for (int o = 8; o > 0; o >>= 1) tm = max(tm, (unsigned int)__shfl_xor((int)tm, o, 64));
-                    if (lane == 0) atomicMin(&tile_max, tm);
-                }
-            }
-    }
-    __syncthreads();
-    for (int p = threadIdx.x; p < kTile * kTile; p += 256) {
-        const int x = px0 + (p & (kTile - 1)), y = py0 + (p >> kTileShift);
-        if (x < W && y < H)
-            resolve_pixel(setup, cell[p], tx, x, y, (size_t)y * W + x, fb, (size_t)y * fb_pitch + x, keep_uncovered != 0, zbuf, ids);
-    }
-}
-
 // word offsets of a RasterTri's fields (the record as 41 consecutive words)
 constexpr int kRecWords = (int)(sizeof(RasterTri) / 4);
 constexpr int kRecEx = (int)(offsetof(RasterTri, ex) / 4), kRecEy = (int)(offsetof(RasterTri, ey) / 4), kRecDx = (int)(offsetof(RasterTri, dx) / 4);
@@ -547,19 +447,27 @@ __device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
     return max(max(a, b), max(c, d));
 }
 
-// The tile kernel with the depth cells in registers.  A wave owns one 32x8 strip of the tile (wave w: rows 8w .. 8w+7),
-// a lane one pixel in each of the strip's four 8x8 blocks (the same row, columns 8 apart), and every wave walks the
-// tile's WHOLE list: a cell has one owner, so the depth test is a compare and a select on the owner's registers (no
-// atomics, no LDS), and the result is the same minimum over {1/z, triangle index} per pixel.  A lane's four pixels
-// share their row, so the row's extent in a triangle (covers()) is worked out once per triangle.  The bounds work as
-// in raster_tile (the largest key of a block's cells, of the strip's cells), kept wave-uniform in scalar registers.
+// The tile kernel: one workgroup per 32x32 tile, the tile's depth cells in registers.  A wave owns one 32x8 strip of
+// the tile (wave w: rows 8w .. 8w+7), a lane one pixel in each of the strip's four 8x8 blocks (the same row, columns
+// 8 apart), and every wave walks the tile's WHOLE list: a cell has one owner, so the depth test is a compare and a
+// select on the owner's registers (no atomics, no LDS), and the result is the minimum over {1/z, triangle index} per
+// pixel.  A lane's four pixels share their row, so the row's extent in a triangle (which columns the reference's scan
+// conversion plots, rasterizer.cpp:143-170) is worked out once per triangle.
+// Per 8x8 block, and for the strip as a whole, the wave keeps an upper bound of the depth keys its cells hold
+// (wave-uniform, in scalar registers).  Cells only ever decrease, so the bound stays valid until it is refreshed; a
+// triangle whose smallest 1/z over the block lies above it cannot win any of the block's pixels (equal 1/z is not
+// skipped: the lower triangle index wins ties) and the block is not tested at all.  1/z is evaluated as
+// (zA*x + zB*y) + zC with every operation rounded, which is monotone in x and in y, so its minimum over a block is
+// taken at a corner, in exactly the arithmetic of the per-pixel test.  The lists are sorted nearest class first, so
+// the bounds drop early and most far triangles are skipped.
 // The list is taken 64 entries at a time, one per lane, to find the triangles that reach into the strip and can still
 // win a pixel; those are then drawn one after the other in list order.  A triangle's record is read by ONE load, lane
-// i taking word i, and its fields are picked out of that register as scalars; the records of the next two
-// candidates are on their way while the current one is drawn (vector loads complete in order, so each is waited for
-// on its own).
+// i taking word i, and its fields are picked out of that register as scalars; the next candidate's record is
+// requested before the current one is drawn.
+// (An earlier form kept the cells in LDS, gave each wave every fourth triangle of the list and tested depth with a
+// 64-bit LDS atomicMin: its waves spent more than half their time waiting for those atomics.)
 template <int NB>      // 8x8 blocks per wave: 4 (a 32x8 strip, 4 waves per tile), 2 (16x8, 8 waves) or 1 (8x8, 16 waves)
-__global__ __launch_bounds__(1024 / NB) void raster_tile_owned(const RasterTri* __restrict__ setup, const uint32_t* __restrict__ tile_start,
+__global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __restrict__ setup, const uint32_t* __restrict__ tile_start,
                                                          const uint32_t* __restrict__ pairs, int tiles_x,
                                                          RasterTextures tx, uint32_t* fb, int fb_pitch, int keep_uncovered, float* zbuf, int32_t* ids,
                                                          int W, int H, uint32_t capacity) {
@@ -600,39 +508,33 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile_owned(const RasterTri* 
             const uint32_t tn = (uint32_t)__builtin_amdgcn_readlane((int)t_lane, __ffsll((long long)from) - 1);
             return lane < kRecWords ? reinterpret_cast<const uint32_t*>(setup + tn)[lane] : 0u;
         };
-        uint32_t rec_a = fetch(todo), rec_b = fetch(todo & (todo - 1ull));
-        while (todo) {
-            const int j = __ffsll((long long)todo) - 1;
-            todo &= todo - 1ull;
-            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)t_lane, j);
-            const uint32_t rec = rec_a;
-            rec_a = rec_b;
-            rec_b = fetch(todo & (todo - 1ull));
+        // draws triangle t, whose record is in `rec`, into this wave's cells
+        auto draw = [&](const uint32_t rec, const uint32_t t) {
             auto wi = [&](int w) { return __builtin_amdgcn_readlane((int)rec, w); };
             auto wf = [&](int w) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)rec, w)); };
             const int tx0 = wi(kRecX0), tx1 = wi(kRecX0 + 1), ty0 = wi(kRecX0 + 2), ty1 = wi(kRecX0 + 3);
             const float zA = wf(kRecZ), zB = wf(kRecZ + 1), zC = wf(kRecZ + 2);
             const int bx0 = max(tx0, sx0) >> 3, bx1 = min(tx1, sx0 + 8 * NB - 1) >> 3;
             const int n_edges = wi(kRecN);
-            // covers() for this lane's row: columns ix0 .. ix1 are plotted (none when ix0 > ix1)
-            int ix0 = 1, ix1 = 0;
-            if (y >= ty0 && y <= ty1) {
-                float xl = (float)(W - 1), xr = 0.0f;
-                bool any = false;
+            // This lane's row: columns ix0 .. ix1 are plotted (none when ix0 > ix1): every edge contributes to the rows it
+            // spans, the row's extent is [min x, max x] over those edges, columns (int)xl+1 .. min(W-2, (int)xr).  Without branches
+            // on what differs between lanes: an edge that does not span the row leaves the extent alone.
+            float xl = (float)(W - 1), xr = 0.0f;
+            bool any = false;
 #pragma unroll
-                for (int e = 0; e < 5; ++e) {
-                    if (e >= n_edges) break;
-                    if (y < wi(kRecIy0 + e) || y > wi(kRecIy1 + e)) continue;
-                    const float xe = wf(kRecEx + e) + wf(kRecDx + e) * (yf - wf(kRecEy + e));
-                    if (xe < xl) xl = xe;
-                    if (xe > xr) xr = xe;
-                    any = true;
-                }
-                if (any) { ix0 = max((int)xl + 1, tx0); ix1 = min(min(W - 2, (int)xr), tx1); }
+            for (int e = 0; e < 5; ++e) {
+                if (e >= n_edges) break;
+                const bool spans = y >= wi(kRecIy0 + e) && y <= wi(kRecIy1 + e);
+                const float xe = wf(kRecEx + e) + wf(kRecDx + e) * (yf - wf(kRecEy + e));
+                xl = (spans && xe < xl) ? xe : xl;
+                xr = (spans && xe > xr) ? xe : xr;
+                any = any || spans;
             }
+            const bool row = any && y >= ty0 && y <= ty1;
+            const int ix0 = row ? max((int)xl + 1, tx0) : 1, ix1 = row ? min(min(W - 2, (int)xr), tx1) : 0;
             const float zrow = zB * yf;
             // Which of the wave's blocks can the triangle still win a pixel in?  Lane 4b + c evaluates 1/z at corner c of
-            // block b (the arithmetic of the per-pixel test, as in raster_tile), two swaps inside the groups of four
+            // block b (the arithmetic of the per-pixel test), two swaps inside the groups of four
             // lanes take the minimum over a block's corners in the order min(min(c0, c1), min(c2, c3)), and one vote
             // collects the blocks that the triangle reaches and whose bound it is not above.
             unsigned int blocks;
@@ -647,15 +549,11 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile_owned(const RasterTri* 
             auto block = [&](int bi, unsigned long long& k, unsigned int& bm) {
                 if (!((blocks >> (4 * bi)) & 1u)) return;
                 const int x = sx0 + (bi << 3) + lx;
-                bool won = false;
-                if (x >= ix0 && x <= ix1) {
-                    const float z0 = zA * (float)x + zrow + zC;
-                    if (z0 < 0.0f) {                    // the z-buffer is cleared to 0 and the test is "z0 >= zbuf: skip" (:55, :177)
-                        const unsigned long long key = ((unsigned long long)orderable(z0) << 32) | t;
-                        won = key < k;
-                        k = won ? key : k;
-                    }
-                }
+                const float z0 = zA * (float)x + zrow + zC;
+                // the z-buffer is cleared to 0 and the test is "z0 >= zbuf: skip" (:55, :177); a negative z0 has its sign bit set
+                const unsigned long long key = ((unsigned long long)~__float_as_uint(z0) << 32) | t;
+                const bool won = x >= ix0 && x <= ix1 && z0 < 0.0f && key < k;
+                k = won ? key : k;
                 if (__any(won)) { bm = wave_max_u32((unsigned int)(k >> 32)); lowered = true; }
             };
             block(0, k0, m0);
@@ -664,8 +562,25 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile_owned(const RasterTri* 
             if (lowered) {
                 const int cb = (lane >> 2) & 3;
                 bound_v = cb == 0 ? m0 : cb == 1 ? m1 : cb == 2 ? m2 : m3;
+                strip_max = NB == 1 ? m0 : NB == 2 ? max(m0, m1) : max(max(m0, m1), max(m2, m3));
             }
-            if (lowered) strip_max = NB == 1 ? m0 : NB == 2 ? max(m0, m1) : max(max(m0, m1), max(m2, m3));
+        };
+        // two records in turn, each in a register of its own: the one being drawn, and the next candidate's, requested
+        // before the drawing starts (vector loads complete in order, so the wait is for the older one only)
+        auto take = [&](unsigned long long& from) -> uint32_t {      // removes the first candidate, returns its triangle
+            const int j = __ffsll((long long)from) - 1;
+            from &= from - 1ull;
+            return (uint32_t)__builtin_amdgcn_readlane((int)t_lane, j);
+        };
+        uint32_t rec_a = fetch(todo);
+        while (todo) {
+            const uint32_t ta = take(todo);
+            const uint32_t rec_b = fetch(todo);
+            draw(rec_a, ta);
+            if (!todo) break;
+            const uint32_t tb = take(todo);
+            rec_a = fetch(todo);
+            draw(rec_b, tb);
         }
     }
     auto resolve = [&](int b, unsigned long long k) {
@@ -894,7 +809,7 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
 #ifndef MRT_RASTER_NB
 #define MRT_RASTER_NB 4
 #endif
-        hipLaunchKernelGGL(raster_tile_owned<MRT_RASTER_NB>, dim3(n_tiles), dim3(1024 / MRT_RASTER_NB), 0, stream, R.d_setup, R.d_tile_start, R.d_pairs, tiles_x, tx,
+        hipLaunchKernelGGL(raster_tile<MRT_RASTER_NB>, dim3(n_tiles), dim3(1024 / MRT_RASTER_NB), 0, stream, R.d_setup, R.d_tile_start, R.d_pairs, tiles_x, tx,
                            fb_direct ? fb_direct : R.d_fb, fb_direct ? pitch_px : W, fb_direct ? 1 : 0,
                            zbuf ? (device_out ? zbuf : R.d_z) : nullptr, tri_ids ? (device_out ? tri_ids : R.d_ids) : nullptr, W, H, capacity);
         RASTER_HIP(hipGetLastError());
