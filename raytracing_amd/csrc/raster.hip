@@ -453,15 +453,15 @@ __device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
 // select on the owner's registers (no atomics, no LDS), and the result is the minimum over {1/z, triangle index} per
 // pixel.  A lane's four pixels share their row, so the row's extent in a triangle (which columns the reference's scan
 // conversion plots, rasterizer.cpp:143-170) is worked out once per triangle.
-// Per 8x8 block, and for the strip as a whole, the wave keeps an upper bound of the depth keys its cells hold
-// (wave-uniform, in scalar registers).  Cells only ever decrease, so the bound stays valid until it is refreshed; a
+// Per 8x8 block the wave keeps an upper bound of the depth keys its cells hold (wave-uniform, in scalar registers).  Cells only ever decrease, so the bound stays valid until it is refreshed; a
 // triangle whose smallest 1/z over the block lies above it cannot win any of the block's pixels (equal 1/z is not
 // skipped: the lower triangle index wins ties) and the block is not tested at all.  1/z is evaluated as
 // (zA*x + zB*y) + zC with every operation rounded, which is monotone in x and in y, so its minimum over a block is
 // taken at a corner, in exactly the arithmetic of the per-pixel test.  The lists are sorted nearest class first, so
 // the bounds drop early and most far triangles are skipped.
-// The list is taken 64 entries at a time, one per lane, to find the triangles that reach into the strip and can still
-// win a pixel; those are then drawn one after the other in list order.  A triangle's record is read by ONE load, lane
+// The list is taken 64 entries at a time, one per lane, to find the triangles that reach into a block of the strip
+// whose bound they are not above; those are then drawn one after the other in list order (each block's bound is
+// looked at again then, before any of the triangle's edges is).  A triangle's record is read by ONE load, lane
 // i taking word i, and its fields are picked out of that register as scalars; the next candidate's record is
 // requested before the current one is drawn.
 // (An earlier form kept the cells in LDS, gave each wave every fourth triangle of the list and tested depth with a
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
     const float yf = (float)y;
     const unsigned long long empty = ((unsigned long long)orderable(0.0f) << 32) | 0xffffffffull;   // the cleared z-buffer, no triangle
     unsigned long long k0 = empty, k1 = empty, k2 = empty, k3 = empty;              // this lane's cells at columns lx, lx + 8, lx + 16, lx + 24
-    unsigned int m0 = orderable(0.0f), m1 = m0, m2 = m0, m3 = m0, strip_max = m0;   // wave-uniform bounds
+    unsigned int m0 = orderable(0.0f), m1 = m0, m2 = m0, m3 = m0;                   // wave-uniform bounds of the four blocks
     const uint32_t begin = tile_start[tile * kDepthClasses], end = min(tile_start[(tile + 1) * kDepthClasses], capacity);
     const float ya = (float)sy0, yb = (float)(sy0 + 7);
     // lane 4b + c (b < NB) looks after corner c of block b in the bound test of every triangle
@@ -494,12 +494,22 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
             t_lane = pairs[base + lane];
             const RasterTri& R = setup[t_lane];
             if (R.y0 <= sy0 + 7 && R.y1 >= sy0 && R.x0 <= sx0 + 8 * NB - 1 && R.x1 >= sx0) {
-                const int x0 = max(R.x0, sx0), x1 = min(R.x1, sx0 + 8 * NB - 1);
-                const float xa = (float)(x0 & ~7), xb = (float)(x1 | 7);
-                const float c0 = R.zA * xa + R.zB * ya + R.zC, c1 = R.zA * xb + R.zB * ya + R.zC;
-                const float c2 = R.zA * xa + R.zB * yb + R.zC, c3 = R.zA * xb + R.zB * yb + R.zC;
-                const float zmin = fminf(fminf(c0, c1), fminf(c2, c3));
-                cand = !(zmin == zmin && orderable(zmin) > strip_max);
+                // block by block, against the bounds as they are now (they only go down while the batch is drawn,
+                // and every block is looked at again then)
+                const int bx0 = max(R.x0, sx0) >> 3, bx1 = min(R.x1, sx0 + 8 * NB - 1) >> 3;
+                const float zya = R.zB * ya, zyb = R.zB * yb;
+                auto open = [&](int bi, unsigned int bm) {
+                    const int bx = (sx0 >> 3) + bi;
+                    if (bx < bx0 || bx > bx1) return false;
+                    const float xa = (float)(bx << 3), xb = (float)((bx << 3) + 7);
+                    const float c0 = R.zA * xa + zya + R.zC, c1 = R.zA * xb + zya + R.zC;
+                    const float c2 = R.zA * xa + zyb + R.zC, c3 = R.zA * xb + zyb + R.zC;
+                    const float zmin = fminf(fminf(c0, c1), fminf(c2, c3));
+                    return !(zmin == zmin && orderable(zmin) > bm);
+                };
+                cand = open(0, m0);
+                if constexpr (NB > 1) cand = cand || open(1, m1);
+                if constexpr (NB > 2) cand = cand || open(2, m2) || open(3, m3);
             }
         }
         unsigned long long todo = __ballot(cand);
@@ -515,6 +525,19 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
             const int tx0 = wi(kRecX0), tx1 = wi(kRecX0 + 1), ty0 = wi(kRecX0 + 2), ty1 = wi(kRecX0 + 3);
             const float zA = wf(kRecZ), zB = wf(kRecZ + 1), zC = wf(kRecZ + 2);
             const int bx0 = max(tx0, sx0) >> 3, bx1 = min(tx1, sx0 + 8 * NB - 1) >> 3;
+            // Which of the wave's blocks can the triangle still win a pixel in?  Lane 4b + c evaluates 1/z at corner c of
+            // block b (the arithmetic of the per-pixel test), two swaps inside the groups of four
+            // lanes take the minimum over a block's corners in the order min(min(c0, c1), min(c2, c3)), and one vote
+            // collects the blocks that the triangle reaches and whose bound it is not above.
+            unsigned int blocks;
+            {
+                const float zc = zA * corner_x + zB * corner_y + zC;
+                float zq = fminf(zc, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zc), 0xB1, 0xf, 0xf, true)));
+                zq = fminf(zq, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zq), 0x4E, 0xf, 0xf, true)));
+                const bool open = corner_block >= bx0 && corner_block <= bx1 && !(zq == zq && orderable(zq) > bound_v);   // a NaN decides nothing
+                blocks = (unsigned int)__ballot(open) & 0x1111u;
+            }
+            if (blocks == 0) return;        // the bounds have dropped below the triangle since the batch was looked through
             const int n_edges = wi(kRecN);
             // This lane's row: columns ix0 .. ix1 are plotted (none when ix0 > ix1): every edge contributes to the rows it
             // spans, the row's extent is [min x, max x] over those edges, columns (int)xl+1 .. min(W-2, (int)xr).  Without branches
@@ -533,18 +556,6 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
             const bool row = any && y >= ty0 && y <= ty1;
             const int ix0 = row ? max((int)xl + 1, tx0) : 1, ix1 = row ? min(min(W - 2, (int)xr), tx1) : 0;
             const float zrow = zB * yf;
-            // Which of the wave's blocks can the triangle still win a pixel in?  Lane 4b + c evaluates 1/z at corner c of
-            // block b (the arithmetic of the per-pixel test), two swaps inside the groups of four
-            // lanes take the minimum over a block's corners in the order min(min(c0, c1), min(c2, c3)), and one vote
-            // collects the blocks that the triangle reaches and whose bound it is not above.
-            unsigned int blocks;
-            {
-                const float zc = zA * corner_x + zB * corner_y + zC;
-                float zq = fminf(zc, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zc), 0xB1, 0xf, 0xf, true)));
-                zq = fminf(zq, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zq), 0x4E, 0xf, 0xf, true)));
-                const bool open = corner_block >= bx0 && corner_block <= bx1 && !(zq == zq && orderable(zq) > bound_v);   // a NaN decides nothing
-                blocks = (unsigned int)__ballot(open) & 0x1111u;
-            }
             bool lowered = false;
             auto block = [&](int bi, unsigned long long& k, unsigned int& bm) {
                 if (!((blocks >> (4 * bi)) & 1u)) return;
@@ -562,7 +573,6 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
             if (lowered) {
                 const int cb = (lane >> 2) & 3;
                 bound_v = cb == 0 ? m0 : cb == 1 ? m1 : cb == 2 ? m2 : m3;
-                strip_max = NB == 1 ? m0 : NB == 2 ? max(m0, m1) : max(max(m0, m1), max(m2, m3));
             }
         };
         // two records in turn, each in a register of its own: the one being drawn, and the next candidate's, requested
