@@ -186,25 +186,28 @@ __device__ __forceinline__ void setup_polygon(const f3* p, const f2* t, int nin,
     T.n = ne;
 }
 
+constexpr uint32_t kSetupSlots = 224;      // records a workgroup of raster_setup stages at a time (four workgroups' arrays fit a CU's LDS)
 __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* pos, const float* uv, const float* N, const int32_t* tri,
                                                      const int32_t* tri_mesh, const int32_t* mesh_tex, RasterTri* out, uint32_t n_tris, uint2* bins, int tiles_x,
                                                      uint32_t* tile_count, uint32_t* big, uint32_t* big_count, float z_near, float z_scale) {
-    // The 164-byte records of a workgroup's 256 triangles are contiguous in memory: they are built in LDS and the
-    // workgroup then writes them as whole cache lines instead of each thread scattering 41 words.  A culled
-    // triangle is in no tile's list, so nobody reads its record and it is not written: only its bin record says so.
+    // The 164-byte records are built in LDS and written from there as runs of consecutive words instead of each
+    // thread scattering 41 words.  Only triangles that face the eye get a staging slot (the others are in no tile's
+    // list, nobody reads their record and it is not written: only their bin record says so), and a workgroup stages
+    // kSetupSlots records at a time: with about half of a scene's triangles facing away one round is the rule, and
+    // the smaller array lets four workgroups share a CU's LDS where one slot per thread allowed three (the kernel
+    // waits for its vertex reads most of the time; its registers allow four).  A workgroup with more front-facing
+    // triangles than slots takes another round.
     constexpr uint32_t kWords = sizeof(RasterTri) / 4, kNWord = offsetof(RasterTri, n) / 4;
-    __shared__ uint32_t stage[256 * kWords];
-    RasterTri& T = reinterpret_cast<RasterTri*>(stage)[threadIdx.x];
+    __shared__ uint32_t stage[kSetupSlots * kWords];
+    __shared__ uint32_t slot_owner[kSetupSlots];       // thread whose triangle a slot holds
     // Triangles a clip plane cuts take the long way (a polygon whose corner count is only known at run time, kept
     // in private memory).  They are few and scattered over the waves, so they are set aside and worked off
     // afterwards by the first threads of the workgroup, side by side in as few waves as they fill.
-    __shared__ uint32_t cut_list[256];
+    __shared__ uint32_t cut_list[256];                 // owner thread | slot << 16
     __shared__ uint32_t cut_count;
-    if (threadIdx.x == 0) cut_count = 0;
-    __syncthreads();
+    __shared__ uint32_t wave_front[4];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = i < n_tris;
-    T.n = 0;
     const int W = F.W, H = F.H;
     struct Corners { f3 p0, p1, p2, Nt; f2 t0, t1, t2; };
     auto corners = [&](uint32_t k) {
@@ -220,52 +223,87 @@ __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* 
         return c;
     };
     const int texture = in_range ? mesh_tex[tri_mesh[i]] : -1;       // -1 when the mesh is culled or has no texture
+    Corners c = {};
+    bool front = false, untouched = true;
     if (texture >= 0) {
-        const Corners c = corners(i);
-        if (!(dot(c.p0, c.Nt) > 0)) {                                          // back-face cull, :113
-            bool untouched = true;                  // every corner on the inner side of both planes (a NaN distance is not)
-            for (int plane = 0; plane < 2; ++plane) {
-                const f3 n = {F.frustum[plane][0], F.frustum[plane][1], F.frustum[plane][2]};
-                const float o = F.frustum[plane][3];
-                untouched = untouched && (dot(n, c.p0) - o >= 0) && (dot(n, c.p1) - o >= 0) && (dot(n, c.p2) - o >= 0);
-            }
+        c = corners(i);
+        front = !(dot(c.p0, c.Nt) > 0);                                        // back-face cull, :113
+        for (int plane = 0; plane < 2; ++plane) {      // every corner on the inner side of both planes (a NaN distance is not)
+            const f3 n = {F.frustum[plane][0], F.frustum[plane][1], F.frustum[plane][2]};
+            const float o = F.frustum[plane][3];
+            untouched = untouched && (dot(n, c.p0) - o >= 0) && (dot(n, c.p1) - o >= 0) && (dot(n, c.p2) - o >= 0);
+        }
+    }
+    // rank of this thread's triangle among the workgroup's front-facing ones
+    const unsigned long long fmask = __ballot(front);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_front[wave] = (uint32_t)__popcll(fmask);
+    if (threadIdx.x == 0) cut_count = 0;
+    __syncthreads();
+    uint32_t rank = (uint32_t)__popcll(fmask & ((1ull << lane) - 1ull)), n_front = 0;
+    for (uint32_t w = 0; w < 4u; ++w) { const uint32_t x = wave_front[w]; n_front += x; if (w < wave) rank += x; }
+    uint2 bin = make_uint2(0u, 0u);
+    bool is_big = false;
+    int cls = 0;
+    TileRange r = {0, 0, 0, 0};
+    for (uint32_t r0 = 0; r0 < n_front; r0 += kSetupSlots) {
+        const bool mine = front && rank >= r0 && rank < r0 + kSetupSlots;
+        const uint32_t slot = rank - r0;
+        if (mine) {
+            RasterTri& T = reinterpret_cast<RasterTri*>(stage)[slot];
+            T.n = 0;
+            slot_owner[slot] = threadIdx.x;
             if (untouched) {
                 // what the two clips make of such a triangle: each hands the corners on rotated by one (clip_against)
                 const f3 q[3] = {c.p2, c.p0, c.p1};
                 const f2 tq[3] = {c.t2, c.t0, c.t1};
                 setup_polygon<3>(q, tq, 3, c.Nt, texture, W, H, T);
             } else {
-                cut_list[atomicAdd(&cut_count, 1u)] = threadIdx.x;
+                cut_list[atomicAdd(&cut_count, 1u)] = threadIdx.x | (slot << 16);
             }
         }
-    }
-    __syncthreads();
-    if (threadIdx.x < cut_count) {
-        const uint32_t owner = cut_list[threadIdx.x], k = blockIdx.x * blockDim.x + owner;
-        const Corners c = corners(k);
-        ClipPoly poly;
-        poly.n = 0;
-        poly.add(c.p0, c.t0); poly.add(c.p1, c.t1); poly.add(c.p2, c.t2);
-        for (int plane = 0; plane < 2; ++plane)
-            poly = clip_against(poly, f3{F.frustum[plane][0], F.frustum[plane][1], F.frustum[plane][2]}, F.frustum[plane][3]);
-        if (poly.n >= 3 && poly.n <= 5)
-            setup_polygon<5>(poly.p, poly.t, poly.n, c.Nt, mesh_tex[tri_mesh[k]], W, H, reinterpret_cast<RasterTri*>(stage)[owner]);
-    }
-    __syncthreads();
-    const int n_edges = T.n;
-    {
-        const uint32_t base = blockIdx.x * 256u, count = min(256u, n_tris - base);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(out + base);
-        for (uint32_t d = threadIdx.x; d < count * kWords; d += 256u)
-            if (stage[(d / kWords) * kWords + kNWord] != 0u) dst[d] = stage[d];
+        __syncthreads();
+        if (threadIdx.x < cut_count) {
+            const uint32_t e = cut_list[threadIdx.x], owner = e & 0xffffu, k = blockIdx.x * blockDim.x + owner;
+            const Corners cc = corners(k);
+            ClipPoly poly;
+            poly.n = 0;
+            poly.add(cc.p0, cc.t0); poly.add(cc.p1, cc.t1); poly.add(cc.p2, cc.t2);
+            for (int plane = 0; plane < 2; ++plane)
+                poly = clip_against(poly, f3{F.frustum[plane][0], F.frustum[plane][1], F.frustum[plane][2]}, F.frustum[plane][3]);
+            if (poly.n >= 3 && poly.n <= 5)
+                setup_polygon<5>(poly.p, poly.t, poly.n, cc.Nt, mesh_tex[tri_mesh[k]], W, H, reinterpret_cast<RasterTri*>(stage)[e >> 16]);
+        }
+        __syncthreads();
+        {
+            const uint32_t n_here = min(kSetupSlots, n_front - r0);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(out + (size_t)blockIdx.x * 256u);
+            for (uint32_t d = threadIdx.x; d < n_here * kWords; d += 256u) {
+                const uint32_t s = d / kWords;
+                if (stage[s * kWords + kNWord] != 0u) dst[slot_owner[s] * kWords + (d - s * kWords)] = stage[d];
+            }
+        }
+        if (mine) {
+            // binning, first pass: the triangle's tile range for the fill pass
+            const RasterTri& T = reinterpret_cast<const RasterTri*>(stage)[slot];
+            if (T.n != 0) {
+                r = tile_range(T);
+                cls = depth_class(T, z_near, z_scale);
+                bin = pack_bin(r, cls);
+                is_big = r.tw * r.th > kSmallTiles;
+            }
+        }
+        if (r0 + kSetupSlots < n_front) {      // another round: the slots are used again
+            __syncthreads();
+            if (threadIdx.x == 0) cut_count = 0;
+            __syncthreads();
+        }
     }
     if (!in_range) return;
-    if (n_edges == 0) { bins[i] = make_uint2(0u, 0u); return; }
-    // binning, first pass: the triangle's tile range for the fill pass, and the tiles' triangle counts
-    const TileRange r = tile_range(T);
-    const int cls = depth_class(T, z_near, z_scale);
-    bins[i] = pack_bin(r, cls);
-    if (r.tw * r.th > kSmallTiles) { big[atomicAdd(big_count, 1u)] = i; return; }
+    bins[i] = bin;
+    if (!bin_drawn(bin)) return;
+    // and the tiles' triangle counts
+    if (is_big) { big[atomicAdd(big_count, 1u)] = i; return; }
     for (int j = 0; j < r.th; ++j)
         for (int k = 0; k < r.tw; ++k) atomicAdd(&tile_count[((r.ty0 + j) * tiles_x + r.tx0 + k) * kDepthClasses + cls], 1u);
 }

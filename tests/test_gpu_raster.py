@@ -55,6 +55,30 @@ def test_raster_soup_matches_oracle():
     rt.close()
 
 
+def test_raster_every_triangle_faces_the_eye():
+    """A soup turned so that no triangle faces away: every workgroup of the set-up kernel then has more triangles to
+    stage than it has staging slots and works in two rounds."""
+    scene = scene_io.soup_scene(3000, seed=21)
+    m = scene["meshes"][0]
+    pos = m["pos"].reshape(-1, 3, 3).copy()
+    uv = m["uv"].reshape(-1, 3, 2).copy()
+    N = m["N"].copy()
+    away = (pos[:, 0] * N).sum(1) > 0                      # rasterizer.cpp:113 with the eye at the origin
+    pos[away] = pos[away][:, [0, 2, 1]]
+    uv[away] = uv[away][:, [0, 2, 1]]
+    N[away] = -N[away]
+    m["pos"], m["uv"], m["N"], m["norm"] = pos.reshape(-1, 3), uv.reshape(-1, 2), N, np.repeat(N, 3, 0)
+    assert not ((pos[:, 0] * N).sum(1) > 0).any()
+    ora = oracle_lib.Oracle()
+    ora.add_scene(scene)
+    ora.build_bvh()
+    rt = Raytracer(640, 360, device=0)
+    rt.build_bvh(scene)
+    frac = _check(rt, ora, oracle_lib.IDENTITY, 640, 360)
+    assert frac > 0.5
+    rt.close()
+
+
 def test_raster_into_page_locked_frame(maze_scene):
     """A caller frame from mrt_host_alloc is written by the kernel itself (covered pixels only, caller's
     pitch): same result as the staged path, pixels outside the frame's width untouched."""
