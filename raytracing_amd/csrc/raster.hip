@@ -491,8 +491,8 @@ __device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
 // select on the owner's registers (no atomics, no LDS), and the result is the minimum over {1/z, triangle index} per
 // pixel.  A lane's four pixels share their row, so the row's extent in a triangle (which columns the reference's scan
 // conversion plots, rasterizer.cpp:143-170) is worked out once per triangle.
-// Per 8x8 block the wave keeps an upper bound of the depth keys its cells hold (wave-uniform, in scalar registers).  Cells only ever decrease, so the bound stays valid until it is refreshed; a
-// triangle whose smallest 1/z over the block lies above it cannot win any of the block's pixels (equal 1/z is not
+// Per 8x8 block the wave keeps an upper bound of the depth keys its cells hold (wave-uniform, in scalar registers).
+// Cells only ever decrease, so the bound stays valid until it is refreshed; a triangle whose smallest 1/z over the block lies above it cannot win any of the block's pixels (equal 1/z is not
 // skipped: the lower triangle index wins ties) and the block is not tested at all.  1/z is evaluated as
 // (zA*x + zB*y) + zC with every operation rounded, which is monotone in x and in y, so its minimum over a block is
 // taken at a corner, in exactly the arithmetic of the per-pixel test.  The lists are sorted nearest class first, so
@@ -525,13 +525,26 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
     const int corner_block = (lane >> 2) < NB ? (sx0 >> 3) + (lane >> 2) : -1;          // -1: this lane's vote never counts
     const float corner_x = (float)((corner_block << 3) + ((lane & 1) ? 7 : 0)), corner_y = (lane & 2) ? yb : ya;
     unsigned int bound_v = orderable(0.0f);                                              // the bound of this lane's block
+    // The list entries and what the 64-wide pass needs of their records (pixel box, 1/z plane) are read ahead: the
+    // entries of the batch after the next and the records of the next batch are requested before the current batch
+    // is looked through and drawn.
+    struct Head { int x0, x1, y0, y1; float zA, zB, zC; };
+    auto entry = [&](uint32_t base) -> uint32_t { return base + lane < end ? pairs[base + lane] : 0xffffffffu; };
+    auto head = [&](uint32_t t) -> Head {
+        Head h = {1, 0, 1, 0, 0.0f, 0.0f, 0.0f};
+        if (t != 0xffffffffu) { const RasterTri& R = setup[t]; h = Head{R.x0, R.x1, R.y0, R.y1, R.zA, R.zB, R.zC}; }
+        return h;
+    };
+    uint32_t t_cur = entry(begin), t_next = entry(begin + 64);
+    Head h_cur = head(t_cur);
     for (uint32_t base = begin; base < end; base += 64) {
-        uint32_t t_lane = 0;
+        const uint32_t t_after = entry(base + 128);
+        const Head h_next = head(t_next);
+        const uint32_t t_lane = t_cur;
         bool cand = false;
-        if (base + lane < end) {
-            t_lane = pairs[base + lane];
-            const RasterTri& R = setup[t_lane];
-            if (R.y0 <= sy0 + 7 && R.y1 >= sy0 && R.x0 <= sx0 + 8 * NB - 1 && R.x1 >= sx0) {
+        {
+            const Head& R = h_cur;
+            if (t_lane != 0xffffffffu && R.y0 <= sy0 + 7 && R.y1 >= sy0 && R.x0 <= sx0 + 8 * NB - 1 && R.x1 >= sx0) {
                 // block by block, against the bounds as they are now (they only go down while the batch is drawn,
                 // and every block is looked at again then)
                 const int bx0 = max(R.x0, sx0) >> 3, bx1 = min(R.x1, sx0 + 8 * NB - 1) >> 3;
@@ -630,6 +643,7 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
             rec_a = fetch(todo);
             draw(rec_b, tb);
         }
+        t_cur = t_next; t_next = t_after; h_cur = h_next;
     }
     auto resolve = [&](int b, unsigned long long k) {
         const int x = sx0 + (b << 3) + lx;
