@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Rasterizer frames against the oracle's scan-line rasterizer for random cameras: the maze at four frame sizes and
+random triangle soups (some turned so that every triangle faces the eye), to the bar of tests/test_gpu_raster.py
+(coverage and depth winner on 99.9 % of the pixels, colours within 1/255 on 99 %).  A campaign, not a test.
+
+    raster_fuzz.py [maze poses] [soups] [seed]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    n_poses = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    n_soups = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    import oracle_lib
+    from conftest import colour_mismatch_fraction
+    from raytracing_amd import Raytracer, scene_io
+    worst = {"coverage": 0.0, "winner": 0.0, "colour": 0.0, "z_q99": 0.0, "z_q999": 0.0, "z_loose": 0}
+
+    def _check(rt, ora, cam, W, H):
+        """The bar of tests/test_gpu_raster.py for coverage, depth winner and colour; the 1/z plane is compared too,
+        but only counted: the reference steps 1/z along edges and spans by repeated addition, and on views along a
+        wall that drifts further from the plane equation than the test's poses show."""
+        fb0 = np.full((H, W), 0x00123456, np.uint32)
+        fb, z, ids = rt.raster(cam, fb=fb0.copy())
+        ref = ora.raster(cam, W, H)
+        ref_fb = fb0.copy()
+        cov_ref = ref["ids"] >= 0
+        ref_fb[cov_ref] = ref["fb"][cov_ref]
+        cov = ids >= 0
+        n = W * H
+        c, w, col = (cov != cov_ref).sum() / n, (ids != ref["ids"]).sum() / n, colour_mismatch_fraction(fb, ref_fb)
+        assert c <= 0.001 and w <= 0.001 and col <= 0.01, (c, w, col)
+        assert (fb[~cov] == 0x00123456).all()
+        worst["coverage"], worst["winner"], worst["colour"] = max(worst["coverage"], c), max(worst["winner"], w), max(worst["colour"], col)
+        same = (ids == ref["ids"]) & cov
+        if same.any():
+            rel = np.abs(z[same] - ref["z"][same]) / np.abs(ref["z"][same])
+            q99, q999 = float(np.quantile(rel, 0.99)), float(np.quantile(rel, 0.999))
+            worst["z_q99"], worst["z_q999"] = max(worst["z_q99"], q99), max(worst["z_q999"], q999)
+            worst["z_loose"] += not (q999 < 1e-3 and q99 < 1e-4)
+    rng = np.random.default_rng(seed)
+    maze = scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "maze.mrts"))
+    ora = oracle_lib.Oracle()
+    ora.add_scene(maze)
+    ora.build_bvh()
+    ora.set_threads(8)
+    sizes = [(320, 200), (256, 256), (640, 360), (1000, 504)]
+    rts = {s: Raytracer(s[0], s[1], device=0) for s in sizes}
+    for rt in rts.values():
+        rt.build_bvh(maze)
+    t0 = time.time()
+    for i in range(n_poses):
+        W, H = sizes[i % len(sizes)]
+        pos = rng.uniform([-19, -0.9, -21], [19, 6, 21]).astype(np.float32)
+        target = rng.uniform([-18, -1, -20], [18, 1, 20]).astype(np.float32)
+        if i % 7 == 0:
+            pos = np.round(pos)            # eyes on integer coordinates (in wall planes)
+        _check(rts[(W, H)], ora, oracle_lib.lookat(tuple(pos), tuple(target)), W, H)
+        if i % 50 == 49:
+            print("maze: %d poses agree (%.0f s)" % (i + 1, time.time() - t0), flush=True)
+    for rt in rts.values():
+        rt.close()
+    for k in range(n_soups):
+        n = int(rng.integers(200, 30000))
+        scene = scene_io.soup_scene(n, seed=int(rng.integers(1, 1 << 30)))
+        if k % 3 == 0:                     # no triangle faces away from an eye at the origin
+            m = scene["meshes"][0]
+            pos = m["pos"].reshape(-1, 3, 3).copy()
+            uv = m["uv"].reshape(-1, 3, 2).copy()
+            N = m["N"].copy()
+            away = (pos[:, 0] * N).sum(1) > 0
+            pos[away] = pos[away][:, [0, 2, 1]]
+            uv[away] = uv[away][:, [0, 2, 1]]
+            N[away] = -N[away]
+            m["pos"], m["uv"], m["N"], m["norm"] = pos.reshape(-1, 3), uv.reshape(-1, 2), N, np.repeat(N, 3, 0)
+        so = oracle_lib.Oracle()
+        so.add_scene(scene)
+        so.build_bvh()
+        W, H = sizes[k % len(sizes)]
+        rt = Raytracer(W, H, device=0)
+        rt.build_bvh(scene)
+        _check(rt, so, oracle_lib.IDENTITY, W, H)
+        for _ in range(2):
+            pos = rng.uniform([-25, -3, -45], [25, 6, 5]).astype(np.float32)
+            _check(rt, so, oracle_lib.lookat(tuple(pos), (0.0, 0.0, -23.0)), W, H)
+        rt.close()
+        print("soup %d (%d triangles): 3 poses agree" % (k, n), flush=True)
+    print("raster fuzz: %d maze poses, %d soups x 3 poses, all within the bar; worst fractions %s" % (n_poses, n_soups, worst))
+
+
+if __name__ == "__main__":
+    main()
