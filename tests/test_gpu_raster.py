@@ -79,6 +79,18 @@ def test_raster_every_triangle_faces_the_eye():
     rt.close()
 
 
+def test_raster_scene_without_triangles():
+    """Nothing to draw: every pixel stays as the caller had it, the id plane says so, 1/z is the cleared buffer's 0."""
+    scene = scene_io.soup_scene(1, seed=3)
+    scene["meshes"] = []
+    rt = Raytracer(96, 64, device=0)
+    rt.build_bvh(scene)
+    fb0 = np.full((64, 96), 0x00123456, np.uint32)
+    fb, z, ids = rt.raster(oracle_lib.IDENTITY, fb=fb0.copy())
+    assert (fb == 0x00123456).all() and (ids == -1).all() and (z == 0).all()
+    rt.close()
+
+
 def test_raster_into_page_locked_frame(maze_scene):
     """A caller frame from mrt_host_alloc is written by the kernel itself (covered pixels only, caller's
     pitch): same result as the staged path, pixels outside the frame's width untouched."""
