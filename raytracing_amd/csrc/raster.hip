@@ -500,8 +500,8 @@ __device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
 // The list is taken 64 entries at a time, one per lane, to find the triangles that reach into a block of the strip
 // whose bound they are not above; those are then drawn one after the other in list order (each block's bound is
 // looked at again then, before any of the triangle's edges is).  A triangle's record is read by ONE load, lane
-// i taking word i, and its fields are picked out of that register as scalars; the next candidate's record is
-// requested before the current one is drawn.
+// i taking word i, and its fields are picked out of that register as scalars; the records of the next two candidates
+// are requested before the current one is drawn.
 // (An earlier form kept the cells in LDS, gave each wave every fourth triangle of the list and tested depth with a
 // 64-bit LDS atomicMin: its waves spent more than half their time waiting for those atomics.)
 template <int NB>      // 8x8 blocks per wave: 4 (a 32x8 strip, 4 waves per tile), 2 (16x8, 8 waves) or 1 (8x8, 16 waves)
@@ -564,10 +564,12 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
             }
         }
         unsigned long long todo = __ballot(cand);
-        auto fetch = [&](unsigned long long from) -> uint32_t {       // the record of the first candidate in `from`
-            if (from == 0) return 0u;
-            const uint32_t tn = (uint32_t)__builtin_amdgcn_readlane((int)t_lane, __ffsll((long long)from) - 1);
-            return lane < kRecWords ? reinterpret_cast<const uint32_t*>(setup + tn)[lane] : 0u;
+        // The record of the candidate in lane j's entry: ONE load, lane i taking word i (the lanes past the record's
+        // end read its last word again).  No branch and no lane mask around it: the loads of a wave complete in order,
+        // and only in straight-line code does the compiler wait for the one it needs instead of for all of them.
+        auto fetch = [&](int j) -> uint32_t {
+            const uint32_t tn = (uint32_t)__builtin_amdgcn_readlane((int)t_lane, j);
+            return reinterpret_cast<const uint32_t*>(setup + tn)[lane < kRecWords ? lane : kRecWords - 1];
         };
         // draws triangle t, whose record is in `rec`, into this wave's cells
         auto draw = [&](const uint32_t rec, const uint32_t t) {
@@ -626,22 +628,37 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
                 bound_v = cb == 0 ? m0 : cb == 1 ? m1 : cb == 2 ? m2 : m3;
             }
         };
-        // two records in turn, each in a register of its own: the one being drawn, and the next candidate's, requested
-        // before the drawing starts (vector loads complete in order, so the wait is for the older one only)
-        auto take = [&](unsigned long long& from) -> uint32_t {      // removes the first candidate, returns its triangle
-            const int j = __ffsll((long long)from) - 1;
-            from &= from - 1ull;
-            return (uint32_t)__builtin_amdgcn_readlane((int)t_lane, j);
-        };
-        uint32_t rec_a = fetch(todo);
-        while (todo) {
-            const uint32_t ta = take(todo);
-            const uint32_t rec_b = fetch(todo);
-            draw(rec_a, ta);
-            if (!todo) break;
-            const uint32_t tb = take(todo);
-            rec_a = fetch(todo);
-            draw(rec_b, tb);
+        // The records of the next two candidates are on their way while a triangle is drawn (past the batch's last
+        // candidate the last record is simply requested again).  Three registers take the three roles in turn, so that
+        // no record is copied from one register to another: a copy would have to wait for the newest load.
+        if (todo) {
+            int j = 0;
+            auto take = [&]() -> uint32_t {        // removes the first candidate from todo, returns its triangle
+                j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                return (uint32_t)__builtin_amdgcn_readlane((int)t_lane, j);
+            };
+            auto ahead = [&]() -> uint32_t {       // the record of the candidate after the next one
+                const unsigned long long from = todo & (todo - 1ull);
+                return fetch(from ? __ffsll((long long)from) - 1 : j);
+            };
+            const int j0 = __ffsll((long long)todo) - 1;
+            const unsigned long long from1 = todo & (todo - 1ull);
+            uint32_t rec_a = fetch(j0), rec_b = fetch(from1 ? __ffsll((long long)from1) - 1 : j0);
+            for (;;) {
+                const uint32_t ta = take();
+                const uint32_t rec_c = ahead();
+                draw(rec_a, ta);
+                if (!todo) break;
+                const uint32_t tb = take();
+                rec_a = ahead();
+                draw(rec_b, tb);
+                if (!todo) break;
+                const uint32_t tc = take();
+                rec_b = ahead();
+                draw(rec_c, tc);
+                if (!todo) break;
+            }
         }
         t_cur = t_next; t_next = t_after; h_cur = h_next;
     }
