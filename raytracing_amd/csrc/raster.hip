@@ -497,7 +497,7 @@ __device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
 // (zA*x + zB*y) + zC with every operation rounded, which is monotone in x and in y, so its minimum over a block is
 // taken at a corner, in exactly the arithmetic of the per-pixel test.  The lists are sorted nearest class first, so
 // the bounds drop early and most far triangles are skipped.
-// The list is taken 64 entries at a time, one per lane, to find the triangles that reach into a block of the strip
+// The list is taken 32 entries at a time, one per lane, to find the triangles that reach into a block of the strip
 // whose bound they are not above; those are then drawn one after the other in list order (each block's bound is
 // looked at again then, before any of the triangle's edges is).  A triangle's record is read by ONE load, lane
 // i taking word i, and its fields are picked out of that register as scalars; the records of the next two candidates
@@ -529,16 +529,19 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
     // entries of the batch after the next and the records of the next batch are requested before the current batch
     // is looked through and drawn.
     struct Head { int x0, x1, y0, y1; float zA, zB, zC; };
-    auto entry = [&](uint32_t base) -> uint32_t { return base + lane < end ? pairs[base + lane] : 0xffffffffu; };
+    // 32 entries at a time (the lower half of the wave): with 64 more of them are dismissed when their turn comes,
+    // because the bounds they were looked through against are older by then
+    constexpr uint32_t kBatch = 32;
+    auto entry = [&](uint32_t base) -> uint32_t { return (uint32_t)lane < kBatch && base + lane < end ? pairs[base + lane] : 0xffffffffu; };
     auto head = [&](uint32_t t) -> Head {
         Head h = {1, 0, 1, 0, 0.0f, 0.0f, 0.0f};
         if (t != 0xffffffffu) { const RasterTri& R = setup[t]; h = Head{R.x0, R.x1, R.y0, R.y1, R.zA, R.zB, R.zC}; }
         return h;
     };
-    uint32_t t_cur = entry(begin), t_next = entry(begin + 64);
+    uint32_t t_cur = entry(begin), t_next = entry(begin + kBatch);
     Head h_cur = head(t_cur);
-    for (uint32_t base = begin; base < end; base += 64) {
-        const uint32_t t_after = entry(base + 128);
+    for (uint32_t base = begin; base < end; base += kBatch) {
+        const uint32_t t_after = entry(base + 2 * kBatch);
         const Head h_next = head(t_next);
         const uint32_t t_lane = t_cur;
         bool cand = false;
