@@ -499,7 +499,7 @@ __device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
 // the bounds drop early and most far triangles are skipped.
 // The list is taken 32 entries at a time, one per lane, to find the triangles that reach into a block of the strip
 // whose bound they are not above; those are then drawn one after the other in list order (each block's bound is
-// looked at again then, before any of the triangle's edges is).  A triangle's record is read by ONE load, lane
+// looked at again then, before the triangle's record is even waited for).  A triangle's record is read by ONE load, lane
 // i taking word i, and its fields are picked out of that register as scalars; the records of the next two candidates
 // are requested before the current one is drawn.
 // (An earlier form kept the cells in LDS, gave each wave every fourth triangle of the list and tested depth with a
@@ -521,10 +521,6 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
     unsigned int m0 = orderable(0.0f), m1 = m0, m2 = m0, m3 = m0;                   // wave-uniform bounds of the four blocks
     const uint32_t begin = tile_start[tile * kDepthClasses], end = min(tile_start[(tile + 1) * kDepthClasses], capacity);
     const float ya = (float)sy0, yb = (float)(sy0 + 7);
-    // lane 4b + c (b < NB) looks after corner c of block b in the bound test of every triangle
-    const int corner_block = (lane >> 2) < NB ? (sx0 >> 3) + (lane >> 2) : -1;          // -1: this lane's vote never counts
-    const float corner_x = (float)((corner_block << 3) + ((lane & 1) ? 7 : 0)), corner_y = (lane & 2) ? yb : ya;
-    unsigned int bound_v = orderable(0.0f);                                              // the bound of this lane's block
     // The list entries and what the 64-wide pass needs of their records (pixel box, 1/z plane) are read ahead: the
     // entries of the batch after the next and the records of the next batch are requested before the current batch
     // is looked through and drawn.
@@ -544,28 +540,32 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
         const uint32_t t_after = entry(base + 2 * kBatch);
         const Head h_next = head(t_next);
         const uint32_t t_lane = t_cur;
-        bool cand = false;
+        // zk0..zk3: per block of the strip, the orderable form of the entry's smallest 1/z over the block (taken at a
+        // corner, in the arithmetic of the per-pixel test); 0 when that is a NaN (a NaN decides nothing: never above a
+        // bound), all ones when the entry does not reach the block (above every bound).  The entry can still win a
+        // pixel of block b while zk_b <= the block's bound: asked now of all entries at once, and again of each
+        // candidate when its turn comes, against the bounds as they are then.
+        unsigned int zk0 = ~0u, zk1 = ~0u, zk2 = ~0u, zk3 = ~0u;
         {
             const Head& R = h_cur;
             if (t_lane != 0xffffffffu && R.y0 <= sy0 + 7 && R.y1 >= sy0 && R.x0 <= sx0 + 8 * NB - 1 && R.x1 >= sx0) {
-                // block by block, against the bounds as they are now (they only go down while the batch is drawn,
-                // and every block is looked at again then)
                 const int bx0 = max(R.x0, sx0) >> 3, bx1 = min(R.x1, sx0 + 8 * NB - 1) >> 3;
                 const float zya = R.zB * ya, zyb = R.zB * yb;
-                auto open = [&](int bi, unsigned int bm) {
+                auto key = [&](int bi) -> unsigned int {
                     const int bx = (sx0 >> 3) + bi;
-                    if (bx < bx0 || bx > bx1) return false;
+                    if (bx < bx0 || bx > bx1) return ~0u;
                     const float xa = (float)(bx << 3), xb = (float)((bx << 3) + 7);
                     const float c0 = R.zA * xa + zya + R.zC, c1 = R.zA * xb + zya + R.zC;
                     const float c2 = R.zA * xa + zyb + R.zC, c3 = R.zA * xb + zyb + R.zC;
                     const float zmin = fminf(fminf(c0, c1), fminf(c2, c3));
-                    return !(zmin == zmin && orderable(zmin) > bm);
+                    return zmin == zmin ? orderable(zmin) : 0u;
                 };
-                cand = open(0, m0);
-                if constexpr (NB > 1) cand = cand || open(1, m1);
-                if constexpr (NB > 2) cand = cand || open(2, m2) || open(3, m3);
+                zk0 = key(0);
+                if constexpr (NB > 1) zk1 = key(1);
+                if constexpr (NB > 2) { zk2 = key(2); zk3 = key(3); }
             }
         }
+        const bool cand = zk0 <= m0 || zk1 <= m1 || zk2 <= m2 || zk3 <= m3;
         unsigned long long todo = __ballot(cand);
         // The record of the candidate in lane j's entry: ONE load, lane i taking word i (the lanes past the record's
         // end read its last word again).  No branch and no lane mask around it: the loads of a wave complete in order,
@@ -575,25 +575,18 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
             return reinterpret_cast<const uint32_t*>(setup + tn)[lane < kRecWords ? lane : kRecWords - 1];
         };
         // draws triangle t, whose record is in `rec`, into this wave's cells
-        auto draw = [&](const uint32_t rec, const uint32_t t) {
+        auto draw = [&](const uint32_t rec, const int j) {
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)t_lane, j);
             auto wi = [&](int w) { return __builtin_amdgcn_readlane((int)rec, w); };
             auto wf = [&](int w) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)rec, w)); };
+            // which of the wave's blocks can the triangle still win a pixel in, now?
+            const unsigned int blocks = ((unsigned int)__builtin_amdgcn_readlane((int)zk0, j) <= m0 ? 0x1u : 0u) |
+                                        ((unsigned int)__builtin_amdgcn_readlane((int)zk1, j) <= m1 ? 0x10u : 0u) |
+                                        ((unsigned int)__builtin_amdgcn_readlane((int)zk2, j) <= m2 ? 0x100u : 0u) |
+                                        ((unsigned int)__builtin_amdgcn_readlane((int)zk3, j) <= m3 ? 0x1000u : 0u);
+            if (blocks == 0) return;        // the bounds have dropped below the triangle since the batch was looked through
             const int tx0 = wi(kRecX0), tx1 = wi(kRecX0 + 1), ty0 = wi(kRecX0 + 2), ty1 = wi(kRecX0 + 3);
             const float zA = wf(kRecZ), zB = wf(kRecZ + 1), zC = wf(kRecZ + 2);
-            const int bx0 = max(tx0, sx0) >> 3, bx1 = min(tx1, sx0 + 8 * NB - 1) >> 3;
-            // Which of the wave's blocks can the triangle still win a pixel in?  Lane 4b + c evaluates 1/z at corner c of
-            // block b (the arithmetic of the per-pixel test), two swaps inside the groups of four
-            // lanes take the minimum over a block's corners in the order min(min(c0, c1), min(c2, c3)), and one vote
-            // collects the blocks that the triangle reaches and whose bound it is not above.
-            unsigned int blocks;
-            {
-                const float zc = zA * corner_x + zB * corner_y + zC;
-                float zq = fminf(zc, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zc), 0xB1, 0xf, 0xf, true)));
-                zq = fminf(zq, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, zq), 0x4E, 0xf, 0xf, true)));
-                const bool open = corner_block >= bx0 && corner_block <= bx1 && !(zq == zq && orderable(zq) > bound_v);   // a NaN decides nothing
-                blocks = (unsigned int)__ballot(open) & 0x1111u;
-            }
-            if (blocks == 0) return;        // the bounds have dropped below the triangle since the batch was looked through
             const int n_edges = wi(kRecN);
             // This lane's row: columns ix0 .. ix1 are plotted (none when ix0 > ix1): every edge contributes to the rows it
             // spans, the row's extent is [min x, max x] over those edges, columns (int)xl+1 .. min(W-2, (int)xr).  Without branches
@@ -612,7 +605,6 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
             const bool row = any && y >= ty0 && y <= ty1;
             const int ix0 = row ? max((int)xl + 1, tx0) : 1, ix1 = row ? min(min(W - 2, (int)xr), tx1) : 0;
             const float zrow = zB * yf;
-            bool lowered = false;
             auto block = [&](int bi, unsigned long long& k, unsigned int& bm) {
                 if (!((blocks >> (4 * bi)) & 1u)) return;
                 const int x = sx0 + (bi << 3) + lx;
@@ -621,25 +613,21 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
                 const unsigned long long key = ((unsigned long long)~__float_as_uint(z0) << 32) | t;
                 const bool won = x >= ix0 && x <= ix1 && z0 < 0.0f && key < k;
                 k = won ? key : k;
-                if (__any(won)) { bm = wave_max_u32((unsigned int)(k >> 32)); lowered = true; }
+                if (__any(won)) bm = wave_max_u32((unsigned int)(k >> 32));
             };
             block(0, k0, m0);
             if constexpr (NB > 1) block(1, k1, m1);
             if constexpr (NB > 2) { block(2, k2, m2); block(3, k3, m3); }
-            if (lowered) {
-                const int cb = (lane >> 2) & 3;
-                bound_v = cb == 0 ? m0 : cb == 1 ? m1 : cb == 2 ? m2 : m3;
-            }
         };
         // The records of the next two candidates are on their way while a triangle is drawn (past the batch's last
         // candidate the last record is simply requested again).  Three registers take the three roles in turn, so that
         // no record is copied from one register to another: a copy would have to wait for the newest load.
         if (todo) {
             int j = 0;
-            auto take = [&]() -> uint32_t {        // removes the first candidate from todo, returns its triangle
+            auto take = [&]() -> int {             // removes the first candidate from todo, returns its lane
                 j = __ffsll((long long)todo) - 1;
                 todo &= todo - 1ull;
-                return (uint32_t)__builtin_amdgcn_readlane((int)t_lane, j);
+                return j;
             };
             auto ahead = [&]() -> uint32_t {       // the record of the candidate after the next one
                 const unsigned long long from = todo & (todo - 1ull);
@@ -649,17 +637,17 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
             const unsigned long long from1 = todo & (todo - 1ull);
             uint32_t rec_a = fetch(j0), rec_b = fetch(from1 ? __ffsll((long long)from1) - 1 : j0);
             for (;;) {
-                const uint32_t ta = take();
+                const int ja = take();
                 const uint32_t rec_c = ahead();
-                draw(rec_a, ta);
+                draw(rec_a, ja);
                 if (!todo) break;
-                const uint32_t tb = take();
+                const int jb = take();
                 rec_a = ahead();
-                draw(rec_b, tb);
+                draw(rec_b, jb);
                 if (!todo) break;
-                const uint32_t tc = take();
+                const int jc = take();
                 rec_b = ahead();
-                draw(rec_c, tc);
+                draw(rec_c, jc);
                 if (!todo) break;
             }
         }
