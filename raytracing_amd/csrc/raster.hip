@@ -5,7 +5,7 @@
 //                     constants and the screen-space plane equations of 1/z, u/z and v/z
 //                     (rasterizer.cpp:100-141); it also counts the triangle into the 32x32-pixel
 //                     screen tiles its pixel bounding box overlaps.
-//   raster_tile_sums, raster_tile_scan, raster_fill_small, raster_bin_big
+//   raster_bin_big, raster_tile_sums, raster_tile_scan, raster_fill
 //                     exclusive scan of the tile counts, then the tiles' triangle lists are filled (a
 //                     triangle overlapping more than 16 tiles is counted and filled by a whole wave,
 //                     lanes striding over its tiles).
@@ -345,7 +345,7 @@ __device__ __forceinline__ void resolve_pixel(const RasterTri* setup, unsigned l
 
 // Binning in two passes.  Counting: raster_setup itself counts the triangles of every tile and lists the
 // big triangles, raster_bin_big<false> counts those.  Filling, after the scan has turned counts into list
-// starts: raster_fill_small and raster_bin_big<true> write the lists (cursor = running fill position per tile).
+// starts: raster_fill writes the lists (cursor = running fill position per tile).
 // A tile's list is kDepthClasses consecutive segments, nearest class first (counts, starts and fill cursors are
 // kept per (tile, class)).  The tile kernel walks the list front to back, so near triangles lower the blocks'
 // depth bounds before the far ones are met, most of which are then skipped.  The order changes no pixel.
@@ -360,21 +360,7 @@ __device__ __forceinline__ void bin_one(uint32_t t, uint32_t slot, uint32_t* til
         if (at < capacity) pairs[at] = t;
     }
 }
-// second pass for the triangles that overlap few tiles: one thread per triangle writes it into its tiles' lists
-__global__ __launch_bounds__(256) void raster_fill_small(const uint2* bins, uint32_t n_tris, int tiles_x, uint32_t* tile_count,
-                                                          const uint32_t* tile_start, uint32_t* pairs, uint32_t capacity) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tris) return;
-    const uint2 b = bins[t];
-    if (!bin_drawn(b)) return;
-    const TileRange r = bin_range(b);
-    if (r.tw * r.th > kSmallTiles) return;
-    const uint32_t cls = bin_class(b);
-    for (int j = 0; j < r.th; ++j)
-        for (int i = 0; i < r.tw; ++i)
-            bin_one<true>(t, (uint32_t)((r.ty0 + j) * tiles_x + r.tx0 + i) * kDepthClasses + cls, tile_count, tile_start, pairs, capacity);
-}
-// triangles that overlap many tiles, one wave each.  FILL = false: count; FILL = true: write the lists
+// triangles that overlap many tiles, one wave each: the counting pass (FILL = false; the filling form is part of raster_fill)
 template <bool FILL>
 __global__ __launch_bounds__(256) void raster_bin_big(const uint2* bins, int tiles_x, uint32_t* tile_count, const uint32_t* tile_start,
                                                        uint32_t* pairs, const uint32_t* big, const uint32_t* big_count, uint32_t capacity) {
@@ -389,6 +375,37 @@ __global__ __launch_bounds__(256) void raster_bin_big(const uint2* bins, int til
             bin_one<FILL>(t, (uint32_t)((r.ty0 + k / r.tw) * tiles_x + r.tx0 + k % r.tw) * kDepthClasses + cls, tile_count, tile_start, pairs,
                           capacity);
     }
+}
+// The second pass, one launch: the first kBigWaves / 4 workgroups take the big triangles, one wave each with the
+// lanes striding over the triangle's tiles (the longest pieces of work start first), the other workgroups the small
+// ones, one thread per triangle.
+__global__ __launch_bounds__(256) void raster_fill(const uint2* bins, uint32_t n_tris, int tiles_x, uint32_t* tile_count, const uint32_t* tile_start,
+                                                    uint32_t* pairs, const uint32_t* big, const uint32_t* big_count, uint32_t capacity) {
+    constexpr uint32_t kBigBlocks = kBigWaves / 4;
+    if (blockIdx.x < kBigBlocks) {
+        const uint32_t n = *big_count;
+        const int lane = threadIdx.x & 63;
+        for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += kBigWaves) {
+            const uint32_t t = big[i];
+            const uint2 b = bins[t];
+            const TileRange r = bin_range(b);
+            const uint32_t cls = bin_class(b);
+            for (int k = lane; k < r.tw * r.th; k += 64)
+                bin_one<true>(t, (uint32_t)((r.ty0 + k / r.tw) * tiles_x + r.tx0 + k % r.tw) * kDepthClasses + cls, tile_count, tile_start, pairs,
+                              capacity);
+        }
+        return;
+    }
+    const uint32_t t = (blockIdx.x - kBigBlocks) * blockDim.x + threadIdx.x;
+    if (t >= n_tris) return;
+    const uint2 b = bins[t];
+    if (!bin_drawn(b)) return;
+    const TileRange r = bin_range(b);
+    if (r.tw * r.th > kSmallTiles) return;
+    const uint32_t cls = bin_class(b);
+    for (int j = 0; j < r.th; ++j)
+        for (int i = 0; i < r.tw; ++i)
+            bin_one<true>(t, (uint32_t)((r.ty0 + j) * tiles_x + r.tx0 + i) * kDepthClasses + cls, tile_count, tile_start, pairs, capacity);
 }
 // Exclusive scan of the list-segment counts in two small launches: raster_tile_sums adds up chunks of kScanChunk
 // consecutive counts (one workgroup each), raster_tile_scan lets every workgroup add the sums of the chunks before
@@ -871,10 +888,8 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
             const dim3 per_tri((R.n_tris + 255) / 256), b256(256);
             // the fill cursors: left at zero by the scan; a second attempt finds them at the counts
             if (attempt > 0) RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_slots + 1) * 4, stream));
-            hipLaunchKernelGGL(raster_fill_small, per_tri, b256, 0, stream, R.d_bins, R.n_tris, tiles_x, R.d_tile_count, R.d_tile_start,
-                               R.d_pairs, capacity);
-            hipLaunchKernelGGL((raster_bin_big<true>), dim3(kBigWaves / 4), b256, 0, stream, R.d_bins, tiles_x, R.d_tile_count, R.d_tile_start,
-                               R.d_pairs, R.d_chunk_base, R.d_total + 1, capacity);
+            hipLaunchKernelGGL(raster_fill, dim3(per_tri.x + kBigWaves / 4), b256, 0, stream, R.d_bins, R.n_tris, tiles_x, R.d_tile_count,
+                               R.d_tile_start, R.d_pairs, R.d_chunk_base, R.d_total + 1, capacity);
         }
 #ifndef MRT_RASTER_NB
 #define MRT_RASTER_NB 4
