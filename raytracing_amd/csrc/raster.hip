@@ -390,9 +390,24 @@ __global__ __launch_bounds__(256) void raster_fill(const uint2* bins, uint32_t n
             const uint2 b = bins[t];
             const TileRange r = bin_range(b);
             const uint32_t cls = bin_class(b);
-            for (int k = lane; k < r.tw * r.th; k += 64)
-                bin_one<true>(t, (uint32_t)((r.ty0 + k / r.tw) * tiles_x + r.tx0 + k % r.tw) * kDepthClasses + cls, tile_count, tile_start, pairs,
-                              capacity);
+            // four tiles per lane at a time: the cursors' atomics return from the memory side, and a wave that waits for
+            // each of them before it issues the next spends its time waiting
+            const int n = r.tw * r.th;
+            for (int k0 = lane; k0 < n; k0 += 256) {
+                uint32_t slot[4], at[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = min(k0 + 64 * u, n - 1);
+                    slot[u] = (uint32_t)((r.ty0 + k / r.tw) * tiles_x + r.tx0 + k % r.tw) * kDepthClasses + cls;
+                    at[u] = k0 + 64 * u < n ? atomicAdd(&tile_count[slot[u]], 1u) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (k0 + 64 * u < n) {
+                        const uint32_t p = tile_start[slot[u]] + at[u];
+                        if (p < capacity) pairs[p] = t;
+                    }
+            }
         }
         return;
     }
