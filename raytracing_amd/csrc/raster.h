@@ -48,7 +48,7 @@ struct RasterState {
     RasterTri* d_setup = nullptr;
     uint2* d_bins = nullptr;          // per triangle: tile range, near / drawn flags (8 bytes; what the binning passes read)
     uint32_t* d_chunk_base = nullptr; // n_tris words: list of the triangles that overlap many tiles
-    uint32_t* d_total = nullptr;     // [0] (tile, triangle) pairs this frame, [1] length of the big-triangle list
+    uint32_t* d_total = nullptr;     // [0] (tile, triangle) pairs this frame, [1] length of the big-triangle list (inside d_tile_count's allocation)
     uint32_t* d_tile_count = nullptr; // per (32x32 tile, depth class): triangle count, then fill cursor
     uint32_t* d_tile_start = nullptr; // per (tile, depth class) (+1): start of its list segment in d_pairs
     uint32_t* d_scan_sums = nullptr;  // sums of chunks of d_tile_count (the scan's first pass)

@@ -30,10 +30,16 @@
 
 namespace mrt {
 
+constexpr int kInlineMeshes = 16;
+constexpr uint32_t kTotalsGap = 64;       // words between the tile counts and the frame's totals
 struct RasterFrame {
     float M[16];             // inverse camera matrix (world -> view), column-major
     float frustum[2][4];     // clip planes 0 (near) and 1 (left): rasterizer.cpp:37-38
     int W, H;
+    // per mesh: texture index, or -1 when the mesh is culled this frame or untextured.  A scene of few meshes carries
+    // the table in the kernel's arguments (n_inline > 0) and needs no copy of it per frame.
+    int n_inline;
+    int mesh_tex_inline[kInlineMeshes];
 };
 
 constexpr uint32_t kUncovered = 0xff000000u;
@@ -222,7 +228,8 @@ __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* 
         c.t0 = {uv[2 * v0], uv[2 * v0 + 1]}; c.t1 = {uv[2 * v1], uv[2 * v1 + 1]}; c.t2 = {uv[2 * v2], uv[2 * v2 + 1]};
         return c;
     };
-    const int texture = in_range ? mesh_tex[tri_mesh[i]] : -1;       // -1 when the mesh is culled or has no texture
+    auto texture_of = [&](uint32_t k) { const int m = tri_mesh[k]; return F.n_inline > 0 ? F.mesh_tex_inline[m] : mesh_tex[m]; };
+    const int texture = in_range ? texture_of(i) : -1;       // -1 when the mesh is culled or has no texture
     Corners c = {};
     bool front = false, untouched = true;
     if (texture >= 0) {
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(256) void raster_setup(RasterFrame F, const float* 
             for (int plane = 0; plane < 2; ++plane)
                 poly = clip_against(poly, f3{F.frustum[plane][0], F.frustum[plane][1], F.frustum[plane][2]}, F.frustum[plane][3]);
             if (poly.n >= 3 && poly.n <= 5)
-                setup_polygon<5>(poly.p, poly.t, poly.n, cc.Nt, mesh_tex[tri_mesh[k]], W, H, reinterpret_cast<RasterTri*>(stage)[e >> 16]);
+                setup_polygon<5>(poly.p, poly.t, poly.n, cc.Nt, texture_of(k), W, H, reinterpret_cast<RasterTri*>(stage)[e >> 16]);
         }
         __syncthreads();
         {
@@ -706,7 +713,7 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
 
 void raster_release(RasterState& R) {
     for (void* p : {(void*)R.d_pos, (void*)R.d_uv, (void*)R.d_N, (void*)R.d_tri, (void*)R.d_tri_mesh, (void*)R.d_mesh_tex, (void*)R.d_setup, (void*)R.d_bins,
-                    (void*)R.d_pairs, (void*)R.d_chunk_base, (void*)R.d_total, (void*)R.d_tile_count, (void*)R.d_tile_start, (void*)R.d_scan_sums,
+                    (void*)R.d_pairs, (void*)R.d_chunk_base, (void*)R.d_tile_count, (void*)R.d_tile_start, (void*)R.d_scan_sums,
                     (void*)R.d_fb, (void*)R.d_z, (void*)R.d_ids})
         if (p) (void)hipFree(p);
     if (R.h_stage) (void)hipHostFree(R.h_stage);
@@ -748,7 +755,6 @@ int raster_upload(RasterState& R, const mrt_mesh* meshes, int n_meshes, hipStrea
     RASTER_HIP(hipMalloc((void**)&R.d_setup, (size_t)R.n_tris * sizeof(RasterTri)));
     RASTER_HIP(hipMalloc((void**)&R.d_bins, (size_t)R.n_tris * sizeof(uint2)));
     RASTER_HIP(hipMalloc((void**)&R.d_chunk_base, (size_t)R.n_tris * 4));
-    RASTER_HIP(hipMalloc((void**)&R.d_total, 16));
     RASTER_HIP(hipMemcpyAsync(R.d_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, stream));
     RASTER_HIP(hipMemcpyAsync(R.d_uv, uv.data(), uv.size() * 4, hipMemcpyHostToDevice, stream));
     RASTER_HIP(hipMemcpyAsync(R.d_N, N.data(), N.size() * 4, hipMemcpyHostToDevice, stream));
@@ -828,24 +834,28 @@ int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const 
     memcpy(F.M, &M, 64);
     for (int p = 0; p < 2; ++p) { F.frustum[p][0] = frustum[p].x; F.frustum[p][1] = frustum[p].y; F.frustum[p][2] = frustum[p].z; F.frustum[p][3] = frustum[p].w; }
     F.W = W; F.H = H;
+    F.n_inline = R.h_mesh_tex.size() <= (size_t)kInlineMeshes ? (int)R.h_mesh_tex.size() : 0;
+    for (int m = 0; m < kInlineMeshes; ++m) F.mesh_tex_inline[m] = m < F.n_inline ? R.h_mesh_tex[(size_t)m] : -1;
     const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile;
     const uint32_t n_tiles = (uint32_t)(tiles_x * tiles_y);
     const uint32_t n_slots = n_tiles * (uint32_t)kDepthClasses;       // one list segment per (tile, depth class)
     if (R.n_tile_slots < n_slots + 1) {
         for (void* p : {(void*)R.d_tile_count, (void*)R.d_tile_start}) if (p) (void)hipFree(p);
-        R.d_tile_count = nullptr; R.d_tile_start = nullptr; R.n_tile_slots = 0;
-        RASTER_HIP(hipMalloc((void**)&R.d_tile_count, (size_t)(n_slots + 1) * 4));
+        R.d_tile_count = nullptr; R.d_tile_start = nullptr; R.d_total = nullptr; R.n_tile_slots = 0;
+        // the frame's two totals live behind the counts, a cache line away from them (the list atomics keep taking
+        // the counts' lines), so that one fill clears both
+        RASTER_HIP(hipMalloc((void**)&R.d_tile_count, (size_t)(n_slots + 1 + kTotalsGap + 4) * 4));
         RASTER_HIP(hipMalloc((void**)&R.d_tile_start, (size_t)(n_slots + 1) * 4));
         if (R.d_scan_sums) (void)hipFree(R.d_scan_sums);
         R.d_scan_sums = nullptr;
         RASTER_HIP(hipMalloc((void**)&R.d_scan_sums, (size_t)((n_slots + kScanChunk - 1) / kScanChunk + 1) * 4));
         R.n_tile_slots = n_slots + 1;
     }
-    RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_slots + 1) * 4, stream));
+    R.d_total = R.d_tile_count + n_slots + 1 + kTotalsGap;
+    RASTER_HIP(hipMemsetAsync(R.d_tile_count, 0, (size_t)(n_slots + 1 + kTotalsGap + 4) * 4, stream));      // counts; totals: [0] pairs, [1] big triangles
     if (R.n_tris > 0) {
         const dim3 per_tri((R.n_tris + 255) / 256), b256(256);
-        RASTER_HIP(hipMemcpyAsync(R.d_mesh_tex, R.h_mesh_tex.data(), R.h_mesh_tex.size() * 4, hipMemcpyHostToDevice, stream));
-        RASTER_HIP(hipMemsetAsync(R.d_total, 0, 16, stream));          // [0] pairs, [1] big triangles
+        if (F.n_inline == 0) RASTER_HIP(hipMemcpyAsync(R.d_mesh_tex, R.h_mesh_tex.data(), R.h_mesh_tex.size() * 4, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(raster_setup, per_tri, b256, 0, stream, F, R.d_pos, R.d_uv, R.d_N, R.d_tri, R.d_tri_mesh, R.d_mesh_tex, R.d_setup, R.n_tris,
                            R.d_bins, tiles_x, R.d_tile_count, R.d_chunk_base, R.d_total + 1, z_near, z_scale);
         hipLaunchKernelGGL((raster_bin_big<false>), dim3(kBigWaves / 4), b256, 0, stream, R.d_bins, tiles_x, R.d_tile_count, R.d_tile_start,
