@@ -367,7 +367,9 @@ struct LaneStack3 {
 // IN the plane of a triangle it passes beside (within about 1e-5 rad: harness in tests/native/check_groups.cpp): all
 // numerators of its test are rounding noise, the reference's verdict for it is noise too, and a box cannot
 // reproduce noise.  Rays that start on a surface meet that case with the surface's own coplanar neighbours, so a
-// secondary or shadow ray within a thousandth of its surface's plane skips nothing.
+// secondary or shadow ray within a thousandth of its surface's plane skips nothing.  Primary rays meet it when the
+// eye lies in a triangle's plane: the frame then hands out the box no ray misses for that triangle's group
+// (eye_grazes_group below).
 __device__ __forceinline__ bool not_grazing(f3 D, f3 surface_normal) { return fabsf(dot(D, surface_normal)) >= 1e-3f; }
 
 __device__ __forceinline__ void group_corners(v4u G, f3& lo, f3& hi) {
@@ -1189,7 +1191,30 @@ __global__ __launch_bounds__(64, MODE == 0 ? MRT_PACKET_WAVES : MRT_RECURSIVE_WA
 
 // The frame's eye-relative copy of the nodes and triangles (SceneGlobalEyeT): one thread per node record and
 // per triangle, the operations of the box and triangle tests in their order.
-__global__ __launch_bounds__(256) void eye_relative_kernel(SceneDev S, float ox, float oy, float oz, float4* eye_nodes, float4* eye_tri, float4* eye_g) {
+// Is the eye within `pad` of the plane of one of the (up to four) triangles of group g?  Primary rays from such an eye
+// can graze that triangle, and a grazing test's verdict is rounding noise that no box predicts (see not_grazing), so
+// the frame gives the group the box no ray misses: the reference tests every ray against every triangle of a leaf
+// (raytracer.cpp:1445-1464, 1328-1346), and so do the frame's primary rays for this group.
+__device__ __forceinline__ bool eye_grazes_group(const SceneDev& S, uint32_t g, f3 O, float pad) {
+    bool near = false;
+    for (uint32_t k = 4u * g; k < 4u * g + 4u && k < (uint32_t)S.n_tris; ++k) {
+        const float4 A = S.triA[k], B = S.triB[k];
+        const float2 C = S.triC[k];
+        near = near || point_near_plane(O, f3{B.z, B.w, C.x}, f3{A.x, A.y, A.z}, f3{A.w, B.x, B.y}, pad);
+    }
+    return near;
+}
+
+// The group boxes as the primary rays of a frame of the recursive shader may use them (the per-lane traversal reads
+// boxes in the scene's own binary16 form): a copy of triG in which the groups the eye grazes are the box no ray misses.
+__global__ __launch_bounds__(256) void eye_groups_kernel(SceneDev S, float ox, float oy, float oz, float pad, uint4* out) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ((uint32_t)S.n_tris + 3u) / 4u) return;
+    out[g] = eye_grazes_group(S, g, f3{ox, oy, oz}, pad) ? make_uint4(MRT_GROUP_EVERYWHERE_X, MRT_GROUP_EVERYWHERE_Y, MRT_GROUP_EVERYWHERE_Z, 0u)
+                                                          : S.triG[g];
+}
+
+__global__ __launch_bounds__(256) void eye_relative_kernel(SceneDev S, float ox, float oy, float oz, float pad, float4* eye_nodes, float4* eye_tri, float4* eye_g) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const f3 O = {ox, oy, oz};
     if (i < 2u * (uint32_t)S.n_node_slots) {
@@ -1214,6 +1239,7 @@ __global__ __launch_bounds__(256) void eye_relative_kernel(SceneDev S, float ox,
         f3 lo, hi;
         group_corners(v4u{g.x, g.y, g.z, g.w}, lo, hi);
         lo = lo - O; hi = hi - O;      // rounding: a ten-millionth of the operands, the padding is 2^-12 of the scene
+        if (eye_grazes_group(S, i, O, pad)) { lo = {-INFINITY, -INFINITY, -INFINITY}; hi = {INFINITY, INFINITY, INFINITY}; }
         eye_g[2 * i] = make_float4(lo.x, lo.y, lo.z, 0.0f);
         eye_g[2 * i + 1] = make_float4(hi.x, hi.y, hi.z, 0.0f);
     }
@@ -1511,10 +1537,20 @@ hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool re
     return mode == 0 ? launch_global_mode<0>(S, F, stream) : launch_global_mode<1>(S, F, stream);
 }
 
-hipError_t launch_eye_relative(const SceneDev& S, const float eye[3], float4* eye_nodes, float4* eye_tri, float4* eye_g, hipStream_t stream) {
+// group_pad: the padding of the scene's group boxes (mrt_scene_upload), also the distance from a triangle's plane
+// within which the eye counts as grazing it
+hipError_t launch_eye_relative(const SceneDev& S, const float eye[3], float group_pad, float4* eye_nodes, float4* eye_tri, float4* eye_g, hipStream_t stream) {
     const uint32_t n = std::max(2u * (uint32_t)S.n_node_slots, (uint32_t)S.n_tris);
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(eye_relative_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, S, eye[0], eye[1], eye[2], eye_nodes, eye_tri, eye_g);
+    hipLaunchKernelGGL(eye_relative_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, S, eye[0], eye[1], eye[2], group_pad, eye_nodes, eye_tri, eye_g);
+    return hipGetLastError();
+}
+
+// S.triG must be set; out: one uint4 per group of four leaf-order slots
+hipError_t launch_eye_groups(const SceneDev& S, const float eye[3], float group_pad, uint4* out, hipStream_t stream) {
+    const uint32_t n = ((uint32_t)S.n_tris + 3u) / 4u;
+    if (n == 0 || !S.triG) return hipSuccess;
+    hipLaunchKernelGGL(eye_groups_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, S, eye[0], eye[1], eye[2], group_pad, out);
     return hipGetLastError();
 }
 

@@ -21,7 +21,8 @@
 
 namespace mrt {
 hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool resident, int n_cus, int resident_threads, hipStream_t stream);
-hipError_t launch_eye_relative(const SceneDev& S, const float eye[3], float4* eye_nodes, float4* eye_tri, float4* eye_g, hipStream_t stream);
+hipError_t launch_eye_relative(const SceneDev& S, const float eye[3], float group_pad, float4* eye_nodes, float4* eye_tri, float4* eye_g, hipStream_t stream);
+hipError_t launch_eye_groups(const SceneDev& S, const float eye[3], float group_pad, uint4* out, hipStream_t stream);
 hipError_t prepare_render_kernels();
 hipError_t launch_depth_view(const SceneDev& S, const FrameDev& F, hipStream_t stream);
 hipError_t launch_order_tiles(const uint32_t* cost, uint32_t* packed, uint32_t* hist, uint32_t* order, int n, hipStream_t stream);
@@ -125,6 +126,11 @@ struct mrt_ctx {
     // scene upload; eye_key = the eye position and scene_serial they were made for
     DevBuf<float4> d_eye_nodes, d_eye_tri, d_eye_g;
     uint32_t eye_key[4] = {0, 0, 0, 0};
+    // the group boxes as the primary rays of the recursive shader may use them from the eye of the last such frame
+    // (kernels.hip: eye_groups_kernel); group_pad = the boxes' padding
+    DevBuf<uint4> d_triG_eye;
+    uint32_t eye_groups_key[4] = {0, 0, 0, 0};
+    float group_pad = 0.0f;
     bool resident = false;      // scene small enough for the LDS-resident kernel
     unsigned scene_serial = 0;  // counts scene uploads
     int n_cus = 256;
@@ -331,12 +337,25 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
         memcpy(key, F.cam, 12);
         key[3] = c->scene_serial;
         if (memcmp(key, c->eye_key, sizeof key) != 0) {
-            MRT_HIP(c, launch_eye_relative(c->scene, F.cam, c->d_eye_nodes.p, c->d_eye_tri.p, c->d_eye_g.p, stream));
+            MRT_HIP(c, launch_eye_relative(c->scene, F.cam, c->group_pad, c->d_eye_nodes.p, c->d_eye_tri.p, c->d_eye_g.p, stream));
             memcpy(c->eye_key, key, sizeof key);
         }
         F.eye_nodes = c->d_eye_nodes.p; F.eye_tri = c->d_eye_tri.p; F.eye_g = c->d_eye_g.p;
     }
-    MRT_HIP(c, launch_render(c->scene, F, mode, resident, c->n_cus, env_int("MRT_RESIDENT_THREADS", kResidentThreads), stream));
+    SceneDev S = c->scene;
+    if (mode == (int)MRT_MODE_RECURSIVE && S.triG) {
+        // the recursive shader's primary rays read the scene's own group boxes: this frame's copy of them stands
+        // back where the eye grazes a triangle (rewritten when the eye or the scene has changed, like the arrays above)
+        uint32_t key[4];
+        memcpy(key, F.cam, 12);
+        key[3] = c->scene_serial;
+        if (memcmp(key, c->eye_groups_key, sizeof key) != 0) {
+            MRT_HIP(c, launch_eye_groups(c->scene, F.cam, c->group_pad, c->d_triG_eye.p, stream));
+            memcpy(c->eye_groups_key, key, sizeof key);
+        }
+        S.triG = c->d_triG_eye.p;
+    }
+    MRT_HIP(c, launch_render(S, F, mode, resident, c->n_cus, env_int("MRT_RESIDENT_THREADS", kResidentThreads), stream));
     MRT_HIP(c, hipEventRecord(c->last_done, stream));
     c->last_stream = stream;
     c->launched = true;
@@ -396,7 +415,7 @@ void mrt_destroy(mrt_ctx* c) {
     c->d_rayO.release(); c->d_rayD.release(); c->d_rayR.release(); c->d_rayT.release(); c->d_rayU.release(); c->d_rayV.release();
     c->d_rayTri.release(); c->d_rayFlag.release();
     c->d_nodes.release(); c->d_triA.release(); c->d_triB.release(); c->d_triC.release(); c->d_attr.release(); c->d_lights.release();
-    c->d_triG.release(); c->d_triM.release(); c->d_eye_nodes.release(); c->d_eye_tri.release(); c->d_eye_g.release();
+    c->d_triG.release(); c->d_triM.release(); c->d_eye_nodes.release(); c->d_eye_tri.release(); c->d_eye_g.release(); c->d_triG_eye.release();
     c->d_tex.release(); c->d_texels.release(); c->d_pal.release(); c->d_objects.release();
     c->d_fb.release(); c->d_ids.release(); c->d_counters.release();
     c->d_tile_cost.release(); c->d_tile_packed.release(); c->d_tile_order.release();
@@ -636,8 +655,9 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     }
     const size_t n_groups = ((size_t)B.n_tris + 3) / 4;
     std::vector<uint4> triG(c->has_groups ? n_groups : 0);
+    c->group_pad = largest * 0x1p-12f;
     if (c->has_groups) {
-        const float pad = largest * 0x1p-12f;
+        const float pad = c->group_pad;
         parallel_for(n_groups, [&](size_t b, size_t e) {
             for (size_t g = b; g < e; ++g) {
                 f3 lo = {INFINITY, INFINITY, INFINITY}, hi = {-INFINITY, -INFINITY, -INFINITY};
@@ -651,7 +671,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
                     }
                 }
                 if (sliver) {           // a box no ray misses
-                    triG[g] = make_uint4(0xfc00fc00u, 0x7c00fc00u, 0x7c007c00u, 0u);
+                    triG[g] = make_uint4(MRT_GROUP_EVERYWHERE_X, MRT_GROUP_EVERYWHERE_Y, MRT_GROUP_EVERYWHERE_Z, 0u);
                     continue;
                 }
                 const uint32_t h[6] = {half_outward(lo.x - pad, false), half_outward(lo.y - pad, false), half_outward(lo.z - pad, false),
@@ -687,6 +707,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     MRT_HIP(c, c->d_eye_nodes.ensure(std::max<size_t>(1, 2 * slots)));
     MRT_HIP(c, c->d_eye_tri.ensure(std::max<size_t>(4, 4 * (size_t)B.n_tris)));
     MRT_HIP(c, c->d_eye_g.ensure(std::max<size_t>(2, 2 * n_groups)));
+    MRT_HIP(c, c->d_triG_eye.ensure(std::max<size_t>(1, n_groups)));
     stage("upload ray-path arrays");
     if (int rc = raster_upload(c->raster, meshes, n_meshes, c->stream, err)) return fail(c, rc, err);
     MRT_HIP(c, hipStreamSynchronize(c->stream));

@@ -145,6 +145,21 @@ MRT_HD bool triangle_is_sliver(f3 p0, f3 p1, f3 p2) {
     return !(nn > 1e-6 * a * b);
 }
 
+// Does the point O lie within `pad` of the plane of the triangle {p0, p0 + e1, p0 + e2}?  A ray that starts there can
+// run IN that plane, where every numerator of the triangle test is rounding noise and no box around the triangle can
+// predict the test's verdict; the frame kernels therefore never skip a group of triangles for primary rays when the eye
+// is near the plane of one of them.  Errs towards "near" (also for a NaN or a triangle without area).
+MRT_HD bool point_near_plane(f3 O, f3 p0, f3 e1, f3 e2, float pad) {
+    const f3 n = cross(e1, e2), d = O - p0;
+    const double nn = (double)n.x * n.x + (double)n.y * n.y + (double)n.z * n.z;
+    const double h = (double)d.x * n.x + (double)d.y * n.y + (double)d.z * n.z;      // distance times |n|
+    return !(h * h > (double)pad * (double)pad * nn);
+}
+// the group box no ray misses (device_scene.h: triG): -infinity .. +infinity on every axis, as three pairs of binary16
+#define MRT_GROUP_EVERYWHERE_X 0xfc00fc00u
+#define MRT_GROUP_EVERYWHERE_Y 0x7c00fc00u
+#define MRT_GROUP_EVERYWHERE_Z 0x7c007c00u
+
 MRT_HD uint32_t f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 MRT_HD float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 

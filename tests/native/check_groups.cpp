@@ -6,6 +6,7 @@
 //    reports a hit, the box test the kernels use (group_touched, restated here in plain C++) must say "touched".
 //    Rays are aimed at points of the triangles from generic origins, so none of them runs inside a triangle's plane
 //    (the case kernels.hip: not_grazing describes); groups holding a sliver get the box no ray misses.
+// 3. Rays that graze a wall (see below): hits hidden without the eye-in-plane guard are counted, none may be with it.
 // usage: check_groups [rays]
 #include <stdio.h>
 #include <stdlib.h>
@@ -108,5 +109,61 @@ int main(int argc, char** argv) {
         }
     }
     printf("rays=%ld skipped=%ld hits=%ld slivers=%ld hidden=%ld\n", tests, skipped_tests, hits, slivers, bad);
-    return bad ? 1 : 0;
+
+    // 3. Grazing rays: four triangles of one wall (coplanar, axis-parallel or slanted), the ray's origin a few float
+    //    steps beside the wall's plane, the ray running along the wall and meeting its plane at 1e-7 ... 1e-3 rad.  All
+    //    numerators of the triangle test are rounding noise for such rays, so a "hit" may be reported far from where
+    //    the ray really crosses the plane, outside the group's box: counted as `grazing_hidden`.  The frame kernels
+    //    therefore give a group the box no ray misses whenever the eye is within the padding of the plane of one of
+    //    its triangles (point_near_plane, the function the kernels call); with that guard nothing may be hidden.
+    long g_tests = 0, g_hits = 0, g_hidden = 0, g_hidden_guarded = 0, g_guarded = 0;
+    for (long n = 0; n < N;) {
+        const float scale = 20.0f, pad = scale * 0x1p-12f;
+        f3 tri[4][3];
+        const f3 c = {uni(-scale, scale), uni(-scale, scale), uni(-scale, scale)};
+        // the wall's plane through c: normal nrm, in-plane axes a and b
+        f3 nrm = (rnd() % 3) ? f3{1, 0, 0} : normalize(f3{uni(-1, 1), uni(-1, 1), uni(-1, 1)});
+        if (rnd() % 3 == 0) nrm = {0, 0, 1};
+        f3 a = normalize(cross(nrm, fabsf(nrm.y) < 0.9f ? f3{0, 1, 0} : f3{1, 0, 0})), b = cross(nrm, a);
+        const float ext = uni(0.5f, 6.0f);
+        for (auto& t : tri) {
+            const float cu = uni(-ext, ext), cv = uni(-ext, ext), sz = uni(0.2f, 3.0f);
+            for (auto& p : t) { const float pu = cu + uni(-sz, sz), pv = cv + uni(-sz, sz); p = c + pu * a + pv * b; }
+        }
+        f3 lo = {INFINITY, INFINITY, INFINITY}, hi = {-INFINITY, -INFINITY, -INFINITY};
+        bool sliver = false;
+        for (auto& t : tri) {
+            sliver = sliver || triangle_is_sliver(t[0], t[1], t[2]);
+            for (auto& p : t) {
+                lo = {std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z)};
+                hi = {std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z)};
+            }
+        }
+        if (sliver) continue;
+        const uint16_t h[6] = {half_outward(lo.x - pad, false), half_outward(lo.y - pad, false), half_outward(lo.z - pad, false),
+                               half_outward(hi.x + pad, true), half_outward(hi.y + pad, true), half_outward(hi.z + pad, true)};
+        for (int k = 0; k < 256; ++k, ++n) {
+            // origin: a point of the plane beside or among the triangles, moved off the plane by a few float steps
+            const float ou = uni(-3 * ext, 3 * ext), ov = uni(-3 * ext, 3 * ext);
+            f3 O = c + ou * a + ov * b;
+            const float off = (rnd() % 4 == 0) ? 0.0f : uni(-1.0f, 1.0f) * powf(10.0f, uni(-7.0f, -1.0f));    // inside and outside the guard's reach
+            O = O + off * nrm;
+            const float ang = uni(0, 6.2831853f), eps = ((rnd() & 1) ? 1.0f : -1.0f) * powf(10.0f, uni(-7.5f, -3.0f));
+            const f3 D = normalize((cosf(ang) * a + sinf(ang) * b) + eps * nrm);
+            const f3 r = 1.0f / D;
+            if (!(fabsf(r.x) < INFINITY && fabsf(r.y) < INFINITY && fabsf(r.z) < INFINITY)) continue;
+            const float tmax = (rnd() % 3 == 0) ? uni(0, 3 * scale) : INFINITY;
+            const bool box = touched(h, O, r, tmax);
+            bool guard = false;
+            for (auto& t : tri) guard = guard || point_near_plane(O, t[0], t[1] - t[0], t[2] - t[0], pad);
+            ++g_tests; g_guarded += guard;
+            for (auto& t : tri) {
+                if (!tri_hit(t[0], t[1], t[2], O, D, tmax)) continue;
+                ++g_hits;
+                if (!box) { ++g_hidden; if (!guard) { if (g_hidden_guarded < 5) printf("hidden from a guarded group: O %a %a %a D %a %a %a\n", O.x, O.y, O.z, D.x, D.y, D.z); ++g_hidden_guarded; } }
+            }
+        }
+    }
+    printf("grazing: rays=%ld guarded=%ld hits=%ld grazing_hidden=%ld hidden_with_guard=%ld\n", g_tests, g_guarded, g_hits, g_hidden, g_hidden_guarded);
+    return (bad || g_hidden_guarded) ? 1 : 0;
 }

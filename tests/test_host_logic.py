@@ -188,14 +188,24 @@ def test_group_boxes_never_hide_a_hit(tmp_path):
     """The boxes around groups of four triangles that let the traversals skip tests in long leaves: binary16 bounds
     rounded outwards contain their value, and over 12 million awkward rays (aimed at vertices, edges and a hair
     beside them, starting on the triangles, axis-parallel, far away; scenes of size 0.05 to 2000) the triangle test
-    never reports a hit for a ray the padded box says it cannot touch."""
+    never reports a hit for a ray the padded box says it cannot touch.  Rays that GRAZE a wall (origin within 1e-7 ... 0.1 of
+    its plane, direction 3e-8 ... 1e-3 rad out of it) are the exception the kernels guard against: the harness finds hits
+    hidden behind the boxes for them, and none once every group whose plane passes within the padding of the origin is
+    given the box no ray misses (mrt_math.h: point_near_plane, the function eye_grazes_group of kernels.hip calls)."""
     import subprocess
     exe = str(tmp_path / "check_groups")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I" + os.path.join(ROOT, "raytracing_amd", "csrc"), "-o", exe,
                            os.path.join(ROOT, "tests", "native", "check_groups.cpp")])
     r = subprocess.run([exe, "24000000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
-    assert "hidden=0" in r.stdout and "skipped=" in r.stdout
+    assert " hidden=0" in r.stdout and "skipped=" in r.stdout
+    import re
+    m = re.search(r"grazing: rays=(\d+) guarded=(\d+) hits=(\d+) grazing_hidden=(\d+) hidden_with_guard=(\d+)", r.stdout)
+    assert m, r.stdout
+    rays, guarded, hits, hidden, hidden_guarded = (int(x) for x in m.groups())
+    assert rays > 20000000 and 0 < guarded < rays and hits > 100000
+    assert hidden > 100, "the harness no longer reaches the case the guard exists for"
+    assert hidden_guarded == 0
 
 
 def test_bvh_builder_under_sanitizers(tmp_path):
