@@ -344,18 +344,22 @@ struct LaneStack1 {
     __device__ __forceinline__ void push(int lane, uint32_t x) { a = (lane == sp) ? x : a; ++sp; }
     __device__ __forceinline__ uint32_t pop() { --sp; return (uint32_t)__builtin_amdgcn_readlane((int)a, sp); }
 };
-struct LaneStack3 {
-    uint32_t a = 0, b = 0, c = 0;
+// Entries of the shared shadow traversal: a node as its two words {firstLeft, count} (what the traversal needs of the
+// node itself, known from its parent's read: taking an entry is then one memory round trip, to the children or the
+// triangles, instead of two) and the lanes whose rays reach it.
+struct LaneStack4 {
+    uint32_t a = 0, b = 0, c = 0, d = 0;
     int sp = 0;
-    __device__ __forceinline__ void push(int lane, uint32_t x, unsigned long long m) {
+    __device__ __forceinline__ void push(int lane, uint32_t first, uint32_t count, unsigned long long m) {
         const bool me = lane == sp;
-        a = me ? x : a; b = me ? (uint32_t)m : b; c = me ? (uint32_t)(m >> 32) : c;
+        a = me ? first : a; b = me ? count : b; c = me ? (uint32_t)m : c; d = me ? (uint32_t)(m >> 32) : d;
         ++sp;
     }
-    __device__ __forceinline__ void pop(uint32_t& x, unsigned long long& m) {
+    __device__ __forceinline__ void pop(uint32_t& first, uint32_t& count, unsigned long long& m) {
         --sp;
-        x = (uint32_t)__builtin_amdgcn_readlane((int)a, sp);
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)b, sp), hi = (uint32_t)__builtin_amdgcn_readlane((int)c, sp);
+        first = (uint32_t)__builtin_amdgcn_readlane((int)a, sp);
+        count = (uint32_t)__builtin_amdgcn_readlane((int)b, sp);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)c, sp), hi = (uint32_t)__builtin_amdgcn_readlane((int)d, sp);
         m = ((unsigned long long)hi << 32) | lo;
     }
 };
@@ -654,17 +658,16 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
     float t = INFINITY;
     Hit h;
     h.tri = -1;
-    LaneStack3 work;
-    work.push(lane, 0u, m);
+    LaneStack4 work;
+    work.push(lane, wbits(root0), wbits(root1), m);
     unsigned long long found = 0;
     while (work.sp > 0) {
         if (wd.expired(16)) break;
-        uint32_t node;
-        work.pop(node, m);
+        uint32_t first, count;
+        work.pop(first, count, m);
         m &= ~found;
         if (m == 0) continue;
         MRT_TICK(wd, 3);
-        const uint32_t first = sc.node_first(node), count = sc.node_count(node);
         if (count != 0) {
             if ((m >> lane) & 1ull) {
                 if (SC::kShadowGroups && sc.has_groups() && count >= (uint32_t)MRT_GROUP_MIN) {
@@ -696,8 +699,7 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
             }
             found = __ballot(h.tri >= 0);
         } else {
-            const uint32_t L = first, Rr = first + 1;
-            const auto pair = sc.siblings(L);
+            const auto pair = sc.siblings(first);
             const v4f l0 = pair[0], l1 = pair[1], r0 = pair[2], r1 = pair[3];
             MRT_TICK(wd, 4);
             bool leftN, rightN;
@@ -708,8 +710,8 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
                 slab_div_pair(l0, l1, r0, r1, R, shortcut, INFINITY, leftN, rightN, a, b);
             }
             const unsigned long long ml = __ballot(leftN) & m, mr = __ballot(rightN) & m;
-            if (mr) work.push(lane, Rr, mr);
-            if (ml) work.push(lane, L, ml);
+            if (mr) work.push(lane, wbits(r0), wbits(r1), mr);
+            if (ml) work.push(lane, wbits(l0), wbits(l1), ml);
         }
     }
     return h.tri >= 0;
@@ -1039,7 +1041,9 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
     if (MODE == 0) {
         const f3 rD = 1.0f / D;
         float t = 100000000;
+        MRT_PHASE_BEGIN(wd);
         traverse_packet(sc, S.n_tris, O, D, rD, t, h, lane, wd);
+        MRT_PHASE_END(wd, 16);
         if constexpr (OBJ) trace_objects(S, O, D, t, h);
         const bool shade = h.tri != -1;
         Surf s;
@@ -1050,7 +1054,9 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
             if (!OBJ || h.tri >= 0) s = fetch_surface(S, h); else s = object_surface(S, -2 - h.tri, hit);
         }
         f4 finalColor = {0, 0, 0, 0};
+        MRT_PHASE_BEGIN(wd);
         direct_light<OBJ, !OBJ>(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
+        MRT_PHASE_END(wd, 17);
         color = shade ? clamp01(finalColor) : MRT_BACKGROUND;
     } else {
         color = shade_recursive<OBJ>(sc, S, O, D, stack, lane, h, n_shadow, n_secondary, wd);

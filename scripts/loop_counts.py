@@ -18,7 +18,7 @@ SITES = {0: "nearest: inner-node step", 1: "nearest: leaf triangle", 2: "nearest
          8: "packet: work item", 9: "packet: inner visit", 10: "packet: leaf triangle", 11: "shader round",
          15: "shadow: inner node exact fallback", 14: "longest wave life | latest scene-copy end", 18: "sum: scene copy clocks | clocks in tiles", 19: "sum: wave life clocks | waves",
          20: "nearest: group box test", 21: "shared leaf: group box test",
-         16: "clocks/16 in nearest-hit traversal", 17: "clocks/16 in direct light + shadow"}
+         16: "clocks/16 in nearest-hit / packet traversal", 17: "clocks/16 in direct light + shadow"}
 
 
 def main():
@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--w", type=int, default=1920)
     ap.add_argument("--h", type=int, default=1080)
     ap.add_argument("--spp-grid", type=int, default=1)
+    ap.add_argument("--scene", default="maze", help="maze | maze+spheres (the two spheres of raytracer.cpp:404-412, lifted to y = 1.5) | "
+                    "soup:N (the large-scene generator) | mixed:N (that soup in three meshes: opaque, mirror, mirror + glass)")
+    ap.add_argument("--pose", default="P0", help="P0 (identity) | P1 | soup (5,1,4) -> (0,0,-20)")
     args = ap.parse_args()
     from raytracing_amd import binding
     binding.LIB_PATH = os.path.join(ROOT, "raytracing_amd", "libmrt_prof.so")
@@ -33,19 +36,50 @@ def main():
     from raytracing_amd import Camera, Raytracer, scene_io
     L = binding.lib()
     L.mrt_debug_loop_counts.argtypes = [C.c_void_p, C.c_void_p]
-    scene = scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "maze.mrts"))
+    objects = None
+    if args.scene.startswith("maze"):
+        scene = scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "maze.mrts"))
+        if args.scene == "maze+spheres":
+            objects = np.float32([[0, 1, 1.5, 0, 0.5, 1, 0, 1, 0, 0.5, 0.0, 1.0, 0], [0, -1, 1.5, 0, 0.5, 1, 1, 1, 1, 0.0, 0.5, 1.5, 0]])
+    else:
+        kind, n = args.scene.split(":")
+        n = int(n)
+        scene = scene_io.soup_scene(n, seed=n if kind == "mixed" else 12345)
+        if kind == "mixed":
+            m = scene["meshes"][0]
+            third, parts = (n // 3) * 3, []
+            for j, (refl, refr, rindex) in enumerate(((0.0, 0.0, 1.0), (0.4, 0.0, 1.0), (0.2, 0.3, 1.5))):
+                lo, hi = j * third // 3, ((j + 1) * third // 3 if j < 2 else n)
+                v0, v1 = lo * 3, hi * 3
+                parts.append({"pos": m["pos"][v0:v1], "uv": m["uv"][v0:v1], "norm": m["norm"][v0:v1], "N": m["N"][lo:hi],
+                              "tri": (m["tri"][lo:hi] - v0).astype(np.int32), "texture": 0,
+                              "bounds": np.concatenate([m["pos"][v0:v1].min(0), m["pos"][v0:v1].max(0)]),
+                              "refl": refl, "refr": refr, "rindex": rindex})
+            scene["meshes"] = parts
     rt = Raytracer(args.w, args.h, device=0)
     rt.build_bvh(scene)
+    if objects is not None:
+        rt.set_objects(objects)
     fb = torch.zeros((args.h, args.w), dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream()
     cam = Camera()
+    if args.pose == "P1":
+        cam.set_position((6, 3, 12))
+        cam.look_at((0, 0, 0))
+    elif args.pose == "soup":
+        cam.set_position((5, 1, 4))
+        cam.look_at((0, 0, -20))
     for mode, name in ((0, "packet"), (1, "recursive")):
         rt.render_device(cam, fb.data_ptr(), args.w, mode=mode, spp_grid=args.spp_grid, stream=stream.cuda_stream)
         torch.cuda.synchronize()
         c = rt.ray_counts()
         out = np.zeros(44, np.uint64)
         L.mrt_debug_loop_counts(rt.h, out.ctypes.data_as(C.c_void_p))
+        rounds = int(out[2 * 11])
         print("%s: %s" % (name, c))
+        if rounds:
+            print("  rays traced per shading round: %.1f of 64 lanes (%d primary + secondary rays, %d rounds)"
+                  % ((c["primary"] + c["secondary"]) / rounds, c["primary"] + c["secondary"], rounds))
         for s in sorted(SITES):
             w, l = int(out[2 * s]), int(out[2 * s + 1])
             if l:
