@@ -245,6 +245,13 @@ int mrt_trace_rays(mrt_ctx* ctx, int n_rays, const float* O, const float* D,
  * out[3] primary hits.  Synchronises the context's last stream. */
 int mrt_get_ray_counts(mrt_ctx* ctx, uint64_t out[4]);
 
+/* How the most recent render's tiles were handed to the GPU's waves: what stands in for the shared tile counter of
+ * threads.cpp:158-169 / raytracer.cpp:436-444.  out[0] = 8x8 tiles of the launch; out[1] = entries its tile queues handed
+ * out -- the same number, or more when the recursive shader's most expensive tiles of the previous frame were handed out
+ * as sixteen 2x2-pixel parts each (15 more entries per such tile) so that a small frame does not wait for one wave.
+ * Synchronises like mrt_get_ray_counts.  The pixels do not depend on any of this. */
+int mrt_get_tile_schedule(mrt_ctx* ctx, uint64_t out[2]);
+
 /* Camera::LookAt (scenedata.h:129-134): out = inverse(lookAt(pos, target, (0,1,0))) with the
  * vendored glm's operation order, so callers can form bit-identical camera matrices. */
 void mrt_camera_look_at(const float pos[3], const float target[3], float out_cam_to_world[16]);

@@ -22,7 +22,7 @@ SYMBOLS = ("mrt_create", "mrt_destroy", "mrt_last_error", "mrt_version", "mrt_sc
            "mrt_set_lights", "mrt_set_objects",
            "mrt_bvh_build_host", "mrt_render", "mrt_host_alloc", "mrt_host_free", "mrt_render_submit", "mrt_render_wait", "mrt_render_device", "mrt_render_device_noalloc", "mrt_render_device_part", "mrt_part_rows",
            "mrt_raster_render", "mrt_raster_render_device", "mrt_trace_packets",
-           "mrt_trace_rays", "mrt_get_ray_counts", "mrt_camera_look_at")
+           "mrt_trace_rays", "mrt_get_ray_counts", "mrt_get_tile_schedule", "mrt_camera_look_at")
 
 
 class MrtError(RuntimeError):
@@ -99,6 +99,8 @@ def lib():
         L.mrt_trace_packets.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
         L.mrt_trace_rays.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
         L.mrt_get_ray_counts.argtypes = [vp, vp]
+        if hasattr(L, "mrt_get_tile_schedule"):         # (absent from older tuning builds named by MRT_LIB)
+            L.mrt_get_tile_schedule.argtypes = [vp, vp]
         L.mrt_camera_look_at.argtypes = [vp, vp, vp]
         L.mrt_camera_look_at.restype = None
         _lib = L
@@ -296,6 +298,12 @@ class Raytracer:
         out = np.zeros(4, np.uint64)
         self._check(self.L.mrt_get_ray_counts(self.h, _p(out)), "mrt_get_ray_counts")
         return {"primary": int(out[0]), "shadow": int(out[1]), "secondary": int(out[2]), "primary_hits": int(out[3])}
+
+    def tile_schedule(self):
+        """mrt_get_tile_schedule: (tiles of the last launch, entries its queues handed out)."""
+        out = np.zeros(2, np.uint64)
+        self._check(self.L.mrt_get_tile_schedule(self.h, _p(out)), "mrt_get_tile_schedule")
+        return int(out[0]), int(out[1])
 
     def raster(self, cam, fb=None, want_z=True, want_ids=True):
         """Rasterizer::Render(camera)."""

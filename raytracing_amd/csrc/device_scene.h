@@ -79,7 +79,8 @@ struct FrameDev {
     int n_queues;            // tile queues of the persistent kernel (set by its launcher: at most one per workgroup)
     uint32_t* fb;            // output frame (output resolution)
     int32_t* hit_ids;        // optional, traced-image resolution
-    // counters[0..15]: [5] watchdog code.  counters[kQueueBase + 16*q]: next index of tile queue q
+    // counters[0..15]: [5] watchdog code, [6] deepest pixel of the BVH-depth view, [7] entries of the tile order list.
+    // counters[kQueueBase + 16*q]: next index of tile queue q
     // (resident kernel), one cache line per queue.
     // Ray statistics live in kStatSlots groups of 16 words (128 bytes, one cache line each) after
     // the queues: group s, word 0 = tiles (low 32 bits; 64 primary rays each) and primary hits (high 32 bits),
@@ -89,7 +90,9 @@ struct FrameDev {
     unsigned long long* counters;
     // Temporal load balancing of the persistent kernel (both optional).  tile_cost[tile]: shader
     // clocks this launch spent on the tile.  tile_order: a permutation of [0, n_tiles), most
-    // expensive tiles of the previous launch first; the queues hand tiles out in that order.
+    // expensive tiles of the previous launch first; the queues hand tiles out in that order.  An entry is
+    // tile | sub << 24: sub 0 = the whole tile, 1 ... 16 = one sixteenth of it (kernels.hip: render_tile), and the
+    // list has counters[kOrderCountSlot] entries.
     uint32_t* tile_cost;
     const uint32_t* tile_order;
     // The scene relative to this frame's eye, for the packet traversal of the primary rays (kernels.hip:
@@ -99,6 +102,8 @@ struct FrameDev {
     const float4* eye_g;
 };
 
+constexpr int kOrderCountSlot = 7;     // counters[7]: entries of the frame's tile order list (tile_order_kernel)
+constexpr int kOrderExtra = 16 * 2048; // entries the list may hold beyond one per tile (tiles handed out as sixteenths)
 constexpr int kStatSlots = 256;
 constexpr int kTileQueues = 32;
 constexpr int kQueueBase = 16;

@@ -237,9 +237,9 @@ __device__ __forceinline__ void slab_div_pair(v4f l0, v4f l1, v4f r0, v4f r1, co
 // [g(tNear~), h(tNear~)] and its tFar in [g(tFar~), h(tFar~)] (e = 2^-21 leaves room for the
 // rounding of g and h themselves), and tFar > 0 iff tFar~ > 0.  Returns false for a lane whose
 // `tFar >= tNear` falls inside the bounds; the caller then evaluates slab_div_pair for the wave.
-__device__ __forceinline__ bool slab_pair_shadow_interval(v4f l0, v4f l1, v4f r0, v4f r1, const RayDiv& R, bool& leftN, bool& rightN) {
+__device__ __forceinline__ bool slab_pair_shadow_interval(v4f l0, v4f l1, v4f r0, v4f r1, const RayDiv& R, bool& leftN, bool& rightN, float& nL, float& nR) {
     constexpr float e = 0x1p-21f;
-    float nL, fL, nR, fR;
+    float fL, fR;
     slab_terms_finite((xyz(l0) - R.O) * R.r, (xyz(l1) - R.O) * R.r, nL, fL);
     slab_terms_finite((xyz(r0) - R.O) * R.r, (xyz(r1) - R.O) * R.r, nR, fR);
     const float nLlo = __builtin_fmaf(-e, fabsf(nL), nL), nLhi = __builtin_fmaf(e, fabsf(nL), nL);
@@ -545,8 +545,26 @@ __device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, 
 // `stack` points at this lane's column of an LDS array laid out [entry][64 lanes].  Lanes
 // first walk inner nodes until each holds a leaf, then all leaves are processed together.
 // ---------------------------------------------------------------------------------------
-template <class SC, typename STP>
-__device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool coords_ok, f3 O, f3 D, bool skip_ok, float& t, Hit& h, STP stack, Watch& wd) {
+// One step of a team's agreement on the nearest hit: the running candidate {t, j} (distance, member that found it)
+// against the candidate of the lane the DPP pattern pairs this lane with; the nearer wins, the lower member on a tie
+// (it tested the earlier triangle: raytracer.cpp:1336-1344 keeps the first of two equal distances).
+template <int DPP>
+__device__ __forceinline__ void team_min_step(float& t, int& j) {
+    // (the members of a team are active together; a lane whose partner were not would see its own candidate)
+    const int ti = __builtin_bit_cast(int, t);
+    const float to = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ti, ti, DPP, 0xf, 0xf, false));
+    const int jo = __builtin_amdgcn_update_dpp(j, j, DPP, 0xf, 0xf, false);
+    const bool take = (to < t) || (to == t && jo < j);
+    t = take ? to : t;
+    j = take ? jo : j;
+}
+
+// TEAM: the 16 lanes of every DPP row carry the SAME ray (render_tile); `lane` is then needed.  Such lanes take the
+// same way through the tree; in a leaf member j tests triangles j, j + 16, ... of it, and the members agree on the
+// nearest hit (the lowest triangle of equal distances) before any of them goes on.
+template <bool TEAM = false, class SC, typename STP>
+__device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool coords_ok, f3 O, f3 D, bool skip_ok, float& t, Hit& h, STP stack, Watch& wd,
+                                                 int lane = 0) {
     h.tri = -1;
     if (n_tris == 0) return false;
     const v4f root0 = sc.node(0), root1 = sc.node(1);
@@ -604,7 +622,25 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
             // that remain is the leaf's.
             uint32_t todo = n_now >= 32u ? ~0u : (1u << n_now) - 1u;
             const bool long_leaf = may_skip && n_now >= (uint32_t)MRT_GROUP_MIN;
-            if (__any(long_leaf)) {
+            if constexpr (TEAM) {
+                // one triangle of the chunk per member
+                static_assert(MRT_LEAF_CHUNK == 16, "a team is the 16 lanes of a DPP row");
+                const float t_before = t;
+                const uint32_t j = (uint32_t)lane & 15u;
+                if (j < n_now) tri_test<false>(sc.tri_a(first + j), sc.tri_b(first + j), sc.tri_c(first + j), O, D, t, h, wd);
+                if (__any(t < t_before)) {          // a member that hit has shortened its t: strictly, as the reference's test demands
+                    float tw = t;
+                    int jw = (int)j;
+                    team_min_step<0xB1>(tw, jw);     // quad_perm [1,0,3,2]
+                    team_min_step<0x4E>(tw, jw);     // quad_perm [2,3,0,1]
+                    team_min_step<0x141>(tw, jw);    // row_half_mirror
+                    team_min_step<0x140>(tw, jw);    // row_mirror
+                    const int from = (lane & 48) | jw;          // the winner (a member whose t is unchanged holds the old hit: equal in all)
+                    t = tw;
+                    h.tri = __shfl(h.tri, from, 64); h.u = __shfl(h.u, from, 64); h.v = __shfl(h.v, from, 64);
+                }
+                todo = 0u;
+            } else if (__any(long_leaf)) {
                 const uint32_t shift = first & 3u, g0 = first >> 2;
                 const uint32_t n_groups = long_leaf ? (shift + n_now + 3u) >> 2 : 0u;     // at most MRT_LEAF_CHUNK / 4 + 1
                 unsigned long long keep = 0;
@@ -644,7 +680,8 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
 // every box test on the way (root gate included), and only those lanes test the leaf.
 // Must be called by all 64 lanes; `take_part` selects the lanes that really have a ray.
 // ---------------------------------------------------------------------------------------
-template <class SC>
+// TEAM: the 16 lanes of every DPP row carry the same ray (render_tile) and share out the triangles of a leaf.
+template <bool TEAM = false, class SC>
 __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coords_ok, f3 O, f3 D, bool take_part, bool skip_ok, int lane, Watch& wd) {
     if (n_tris == 0) return false;
     const v4f root0 = sc.node(0), root1 = sc.node(1);
@@ -669,7 +706,16 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
         if (m == 0) continue;
         MRT_TICK(wd, 3);
         if (count != 0) {
-            if ((m >> lane) & 1ull) {
+            if constexpr (TEAM) {
+                // member j of a team tests triangles j, j + 16, ... of the leaf; one member's hit is the team's answer
+                for (uint32_t k0 = first; k0 < first + count; k0 += 16u) {
+                    const uint32_t k = k0 + ((uint32_t)lane & 15u);
+                    if (((m >> lane) & 1ull) && k < first + count && h.tri < 0) tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
+                    const unsigned long long hits = __ballot(h.tri >= 0);
+                    if ((hits >> (lane & 48)) & 0xffffull) h.tri = 0;
+                    if (!__any(h.tri < 0 && ((m >> lane) & 1ull))) break;
+                }
+            } else if ((m >> lane) & 1ull) {
                 if (SC::kShadowGroups && sc.has_groups() && count >= (uint32_t)MRT_GROUP_MIN) {
                     walk_leaf_by_groups<false>(sc, first, count, O, R.r, r_ok, t, wd, [&](uint32_t k) {
                         MRT_TICK(wd, 5);
@@ -703,15 +749,27 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
             const v4f l0 = pair[0], l1 = pair[1], r0 = pair[2], r1 = pair[3];
             MRT_TICK(wd, 4);
             bool leftN, rightN;
-            const bool sure = shortcut && slab_pair_shadow_interval(l0, l1, r0, r1, R, leftN, rightN);
+            float nl = 0.0f, nr = 0.0f;          // entry distances (estimates will do: they only order the two children)
+            const bool sure = shortcut && slab_pair_shadow_interval(l0, l1, r0, r1, R, leftN, rightN, nl, nr);
             if (__any(((m >> lane) & 1ull) && !sure)) {
                 MRT_TICK(wd, 15);
-                float a, b;
-                slab_div_pair(l0, l1, r0, r1, R, shortcut, INFINITY, leftN, rightN, a, b);
+                slab_div_pair(l0, l1, r0, r1, R, shortcut, INFINITY, leftN, rightN, nl, nr);
             }
             const unsigned long long ml = __ballot(leftN) & m, mr = __ballot(rightN) & m;
-            if (mr) work.push(lane, wbits(r0), wbits(r1), mr);
-            if (ml) work.push(lane, wbits(l0), wbits(l1), ml);
+#ifdef MRT_SHADOW_NEAR_FIRST
+            // Any order gives the same answer; the child most of the rays enter first is the likelier one to block them
+            // soon, and a ray that is blocked leaves the traversal.
+            const unsigned long long both = ml & mr;
+            const bool right_first = both != 0 && 2 * __popcll(__ballot(nr < nl) & both) > __popcll(both);
+            if (right_first) {
+                if (ml) work.push(lane, wbits(l0), wbits(l1), ml);
+                if (mr) work.push(lane, wbits(r0), wbits(r1), mr);
+            } else
+#endif
+            {
+                if (mr) work.push(lane, wbits(r0), wbits(r1), mr);
+                if (ml) work.push(lane, wbits(l0), wbits(l1), ml);
+            }
         }
     }
     return h.tri >= 0;
@@ -837,7 +895,7 @@ __device__ __forceinline__ Surf object_surface(const SceneDev& S, int k, f3 hit)
 // ray per light, starting exactly on the surface (no epsilon).  Must be called by all 64 lanes.
 // REMAKE_COLOUR: the surface colour is made again from the packed palette entry after every shadow traversal
 // instead of being kept in four registers across it (the packet kernel is compiled for 64 registers).
-template <bool OBJ, bool REMAKE_COLOUR, class SC>
+template <bool OBJ, bool REMAKE_COLOUR, bool TEAM = false, class SC>
 __device__ __forceinline__ void direct_light(const SC& sc, const SceneDev& S, bool shade, const Surf& s, f3 hit, f4& finalColor,
                                              int lane, uint32_t& n_shadow, Watch& wd) {
     const float lightStrength = shade ? 1.0f - (s.refr + s.refl) : 0.0f;
@@ -851,7 +909,7 @@ __device__ __forceinline__ void direct_light(const SC& sc, const SceneDev& S, bo
     for (int i = 0; i < S.n_lights; ++i) {
         const float4 lp = S.lights[2 * i];
         const f3 L = lit ? normalize(xyz(lp) - hit) : f3{0.0f, 0.0f, 1.0f};
-        bool occluded = occluded_wave(sc, S.n_tris, S.coords_ok != 0, hit, L, lit, not_grazing(L, s.normal), lane, wd);
+        bool occluded = occluded_wave<TEAM>(sc, S.n_tris, S.coords_ok != 0, hit, L, lit, not_grazing(L, s.normal), lane, wd);
         if constexpr (OBJ) { if (lit && !occluded) occluded = objects_occlude(S, hit, L); }
         const float4 lc = S.lights[2 * i + 1];         // read after the traversal: nothing to keep alive across it
         f4 colorP = s.colorP;
@@ -897,7 +955,7 @@ struct ShadeState {
     int stage;      // 0: reflection not tried yet, 1: refraction not tried yet, 2: done
 };
 
-template <bool OBJ, class SC, typename STP>
+template <bool OBJ, bool TEAM, class SC, typename STP>
 __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f3 O, f3 D, STP stack, int lane, Hit& primary,
                                               uint32_t& n_shadow, uint32_t& n_secondary, Watch& wd) {
     float frames[kFrames][kFrameWords];
@@ -915,7 +973,7 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
         float t = tmax;
         bool isHit = false;
         MRT_PHASE_BEGIN(wd);
-        if (tracing) isHit = traverse_nearest(sc, S.n_tris, S.coords_ok != 0, O, D, skip_ok, t, h, stack, wd);
+        if (tracing) isHit = traverse_nearest<TEAM>(sc, S.n_tris, S.coords_ok != 0, O, D, skip_ok, t, h, stack, wd, lane);
         if constexpr (OBJ) { if (tracing) { trace_objects(S, O, D, t, h); isHit = h.tri != -1; } }
         MRT_PHASE_END(wd, 16);
         if (tracing && first) { primary = h; first = false; }
@@ -929,7 +987,7 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
         }
         f4 finalColor = {0, 0, 0, 0};
         MRT_PHASE_BEGIN(wd);
-        direct_light<OBJ, false>(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
+        direct_light<OBJ, false, TEAM>(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
         MRT_PHASE_END(wd, 17);
         if (!tracing) continue;
         tracing = false;
@@ -1013,9 +1071,22 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // ---------------------------------------------------------------------------------------
 // One tile: ray generation (threads.cpp:189-211), trace, shade, pixel pack + store
 // (threads.cpp:215-224).  MODE 0 = packet path, 1 = recursive shader.  All 64 lanes call it.
+// sub: 0 = the whole tile; 1 ... 16 (recursive shader without a sample grid only) = one sixteenth of it, the 2x2 pixels
+// at column 2 * ((sub - 1) % 4), row 2 * ((sub - 1) / 4) of the tile.  A pixel's ray tree depends on nothing but its
+// own ray (raytracer.cpp:575-664), so sixteen such calls write the tile's pixels.
 // ---------------------------------------------------------------------------------------
-template <int MODE, bool OBJ, class SC, typename STP>
-__device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, const FrameDev& F, int tile, int lane, STP stack) {
+template <int MODE, bool OBJ, bool TEAM = false, class SC, typename STP>
+__device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, const FrameDev& F, int tile, int lane, STP stack, int sub = 0) {
+    // A sixteenth of a tile is four pixels for 64 lanes: every pixel gets a TEAM of 16 lanes (one DPP row) that all
+    // carry the pixel's ray.  They walk the tree side by side (same ray, same decisions) and share out the triangles of
+    // a leaf among themselves (traverse_nearest), which is what shortens the walk of a single ray tree; member 0 of a
+    // team writes the pixel and counts its rays.
+    constexpr bool team = TEAM;          // (instantiated apart: whole tiles run the code they always ran; sub != 0 exactly when TEAM)
+    auto pixel_of = [&](int l) {       // the tile's pixel (0 ... 63, row-major) lane l works for
+        return team ? (2 * ((sub - 1) >> 2) + (l >> 5)) * 8 + 2 * ((sub - 1) & 3) + ((l >> 4) & 1) : l;
+    };
+    const bool writer = !team || (lane & 15) == 0;
+    int pl = pixel_of(lane);
     const int ltr = tile / F.tiles_x, tx = tile - ltr * F.tiles_x;   // ltr: tile row within this launch
     int ty = F.tile_y0 + ltr;
     if (F.n_parts > 1) {
@@ -1023,8 +1094,8 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
         const int blk = lr / F.part_block;
         ty = ((blk * F.n_parts + F.part) * F.part_block + (lr - blk * F.part_block)) * F.grid_g + sub;
     }
-    int x = tx * 8 + (lane & 7);
-    const int y = ty * 8 + (lane >> 3);
+    int x = tx * 8 + (pl & 7);
+    const int y = ty * 8 + (pl >> 3);
 
     const f3 p0 = {F.p0[0], F.p0[1], F.p0[2]}, d10 = {F.d10[0], F.d10[1], F.d10[2]}, d20 = {F.d20[0], F.d20[1], F.d20[2]};
     const f3 O = {F.cam[0], F.cam[1], F.cam[2]};
@@ -1059,7 +1130,8 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
         MRT_PHASE_END(wd, 17);
         color = shade ? clamp01(finalColor) : MRT_BACKGROUND;
     } else {
-        color = shade_recursive<OBJ>(sc, S, O, D, stack, lane, h, n_shadow, n_secondary, wd);
+        color = shade_recursive<OBJ, TEAM>(sc, S, O, D, stack, lane, h, n_shadow, n_secondary, wd);
+        if (!writer) { n_shadow = 0; n_secondary = 0; }
     }
     const uint32_t px = vec_to_pixel(color);
 
@@ -1068,13 +1140,14 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
     {
         int lane_again = lane;
         asm volatile("" : "+v"(lane_again));
-        x = tx * 8 + (lane_again & 7);
+        pl = pixel_of(lane_again);
+        x = tx * 8 + (pl & 7);
     }
-    const int y_store = (F.compact ? ltr : ty) * 8 + (lane >> 3);    // row of the traced image as laid out in fb / hit_ids
-    if (F.hit_ids) F.hit_ids[(size_t)y_store * F.width + x] = h.tri;
+    const int y_store = (F.compact ? ltr : ty) * 8 + (pl >> 3);    // row of the traced image as laid out in fb / hit_ids
+    if (F.hit_ids && writer) F.hit_ids[(size_t)y_store * F.width + x] = h.tri;
     const int g = F.grid_g;
     if (g == 1) {
-        F.fb[(size_t)y_store * F.pitch + x] = px;
+        if (writer) F.fb[(size_t)y_store * F.pitch + x] = px;
     } else {
         // box filter over g x g blocks of QUANTISED pixels, rounded down per channel
         uint32_t ar = ((px >> 24) << 16) | ((px >> 16) & 255u);      // A | R   (16 bits each)
@@ -1096,7 +1169,7 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
     }
 #endif
     if (F.stats) {
-        const uint32_t hits = (uint32_t)__popcll(__ballot(h.tri != -1));
+        const uint32_t hits = (uint32_t)__popcll(__ballot(writer && h.tri != -1));
         const uint32_t sh = wave_sum(n_shadow), se = wave_sum(n_secondary);
         if (lane == 0) {
             unsigned long long* slot = F.counters + kStatBase + 16 * (tile % kStatSlots);
@@ -1104,7 +1177,7 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
             // sends as few as it can: one word carries the tile count (low half) and the primary hits (high
             // half); shadow rays are sent as the difference from "one per primary hit and light", which is zero
             // for a tile of the packet path on opaque-or-lit surfaces, and secondary rays only when there are any.
-            atomicAdd(&slot[0], 1ull | ((unsigned long long)hits << 32));
+            atomicAdd(&slot[0], (sub <= 1 ? 1ull : 0ull) | ((unsigned long long)hits << 32));      // (a tile in sixteenths is counted once)
             const long long extra_shadow = (long long)sh - (long long)hits * S.n_lights;
             if (extra_shadow) atomicAdd(&slot[1], (unsigned long long)extra_shadow);
             if (se) atomicAdd(&slot[2], (unsigned long long)se);
@@ -1357,20 +1430,28 @@ __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_t
     // (Measured and dropped: pulling the next tile while the current one renders, which hides the pull's
     // round trip to the L2 -- 8 % slower, because with the expensive tiles handed out first a tile reserved
     // early waits behind an expensive one.)
+    // What the queues hand out: the frame's tiles, or (F.tile_order) the entries of the list tile_order_kernel made:
+    // tile | sub << 24, a whole tile or one sixteenth of an expensive one; counters[kOrderCountSlot] holds their number.
     const int n_queues = F.n_queues;
     const int q = (int)(blockIdx.x % (unsigned)n_queues);
-    for (int pulls = 0; pulls <= F.n_tiles; ++pulls) {   // bounded: no wave can draw more
+    const long long n_pos = F.tile_order ? (long long)F.counters[kOrderCountSlot] : (long long)F.n_tiles;
+    for (long long pulls = 0; pulls <= n_pos; ++pulls) {   // bounded: no wave can draw more
         unsigned long long next = 0;
         if (lane == 0) next = atomicAdd(&F.counters[kQueueBase + 16 * q], 1ull);
         const int idx = __builtin_amdgcn_readfirstlane((int)next);
         const long long pos = (long long)idx * n_queues + q;
-        if (pos >= (long long)F.n_tiles) break;
-        const int tile = F.tile_order ? (int)F.tile_order[pos] : pos;
+        if (pos >= n_pos) break;
+        const uint32_t entry = F.tile_order ? F.tile_order[pos] : (uint32_t)pos;
+        const int tile = (int)(entry & 0xffffffu), sub = (int)(entry >> 24);
         const unsigned long long t0 = __builtin_readcyclecounter();
-        render_tile<MODE, false>(sc, S, F, tile, lane, stack);
+        if (MODE == 1 && sub != 0) render_tile<MODE, false, MODE == 1>(sc, S, F, tile, lane, stack, sub);
+        else render_tile<MODE, false>(sc, S, F, tile, lane, stack);
         if (F.tile_cost && lane == 0) {
             const unsigned long long dt = __builtin_readcyclecounter() - t0;
-            F.tile_cost[tile] = dt > 0xffffffffull ? 0xffffffffu : (uint32_t)dt;
+            const uint32_t c = dt > 0x3fffffffull ? 0x3fffffffu : (uint32_t)dt;
+            // a whole tile's clocks, or (bit 31) those of a tile's slowest sixteenth: see tile_keys_kernel
+            if (sub == 0) F.tile_cost[tile] = c;
+            else atomicMax(&F.tile_cost[tile], c | 0x80000000u);
         }
 #ifdef MRT_LOOP_COUNTS
         t_tiles += __builtin_readcyclecounter() - t0;
@@ -1416,42 +1497,121 @@ __device__ __forceinline__ uint32_t cost_key(uint32_t cost) {
     const uint32_t k = b > (127u << 3) ? b - (127u << 3) : 0u;         // cost 1 -> 0, cost 2^32 -> 256
     return 255u - (k > 255u ? 255u : k);                                // expensive first
 }
-__global__ __launch_bounds__(1024) void tile_keys_kernel(const uint32_t* cost, uint32_t* packed, uint32_t* hist, int n) {
+// cost[i]: what the previous launch left for tile i -- its shader clocks if it was rendered whole, or, with bit 31 set,
+// the clocks of its slowest sixteenth.  A sixteenth takes 0.4 to 0.9 of its tile's time, differently from tile to tile,
+// so state[i] keeps the tile's estimate (bits 8-31, units of 64 clocks) together with the ratio sixteenth : whole
+// (bits 0-7, in 1/256; 0 = not known) as measured in the first frame that split the tile, when the whole tile's cost
+// was known from the frame before; while the tile stays split, estimate = slowest sixteenth / ratio.  (One fixed ratio
+// for all tiles made the tiles it flattered fall under the splitting threshold and come back every other frame.)
+__global__ __launch_bounds__(1024) void tile_keys_kernel(uint32_t* cost, uint32_t* state, uint32_t* packed, uint32_t* hist, int n) {
     __shared__ uint32_t count[256], base[256];
     const int t = threadIdx.x, i = (int)blockIdx.x * 1024 + t;
     if (t < 256) count[t] = 0;
     __syncthreads();
-    const uint32_t key = i < n ? cost_key(cost[i]) : 0u;
+    uint32_t key = 0u;
+    if (i < n) {
+        const uint32_t c = cost[i];
+        uint32_t whole = c, ratio = 0u;
+        if (c >> 31) {
+            const uint32_t part = c & 0x7fffffffu, st = state[i], before = (st >> 8) << 6;
+            ratio = st & 255u;
+            if (ratio == 0u) {
+                const unsigned long long r = ((unsigned long long)part << 8) / (before ? before : 1u);
+                ratio = r < 64u ? 64u : (r > 255u ? 255u : (uint32_t)r);
+            }
+            const unsigned long long w = ((unsigned long long)part << 8) / ratio;
+            whole = w > 0x3fffffffull ? 0x3fffffffu : (uint32_t)w;
+        }
+        state[i] = ((whole >> 6) << 8) | ratio;
+        cost[i] = 0u;            // the sixteenths of a tile leave their maximum (atomicMax)
+        key = cost_key(whole);
+    }
     const uint32_t local = i < n ? atomicAdd(&count[key], 1u) : 0u;
     __syncthreads();
     if (t < 256 && count[t]) base[t] = atomicAdd(&hist[t], count[t]);
     __syncthreads();
     if (i < n) packed[i] = (key << 24) | (base[key] + local);
 }
-__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* packed, const uint32_t* hist, uint32_t* order, int n) {
-    __shared__ uint32_t first[256];
+// Splitting the most expensive tiles.  A frame cannot end before its most expensive tile has, and a tile is one wave
+// that walks its pixels' ray trees one ray after the other: below about a million pixels the frame takes as long as
+// that one tile while most of the chip idles.  A wave with only a 2x2 block of the tile's pixels live finishes in about
+// 0.6 of the time (the longest ray tree still has to be walked), so the tiles within 6/8 octave of the most expensive one
+// are handed out as sixteen entries -- if they also cost more than twice what a wave has to do on average anyway (a large
+// frame is bound by the sum of the work, which splitting multiplies by ten for the tiles it splits), and only as many of
+// them, most expensive first, as the chip has time for while the slowest sixteenth runs (without that limit the extra
+// waves slow every tile down, more tiles look expensive, and the number of split tiles runs away: measured).
+//   n_waves: waves the coming launch will run; capacity: entries `order` can hold; n_entries: where the length of the list goes
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* packed, const uint32_t* hist, uint32_t* order, int n,
+                                                          int allow_split, int n_waves, float budget_frac, uint32_t split_keys, uint32_t capacity, unsigned long long* n_entries) {
+    __shared__ uint32_t first[256], mult[256];
     const int t = threadIdx.x, i = (int)blockIdx.x * 1024 + t;
-    if (t < 64) {            // one wave: exclusive prefix sum of the 256 counts, four per lane
-        const uint32_t c0 = hist[4 * t], c1 = hist[4 * t + 1], c2 = hist[4 * t + 2], c3 = hist[4 * t + 3];
-        uint32_t incl = c0 + c1 + c2 + c3;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_up(incl, o, 64);
-            if (t >= o) incl += up;
+    if (t < 64) {            // one wave: four keys per lane
+        uint32_t c[4], m[4];
+        float work = 0.0f;
+        uint32_t kmin = 1024u;
+        for (int j = 3; j >= 0; --j) {
+            c[j] = hist[4 * t + j];
+            work += (float)c[j] * exp2f((float)(255 - (4 * t + j)) * 0.125f);       // cost_key: one key per 1/8 octave, expensive first
+            if (c[j]) kmin = (uint32_t)(4 * t + j);
         }
-        const uint32_t excl = incl - (c0 + c1 + c2 + c3);
-        first[4 * t] = excl; first[4 * t + 1] = excl + c0; first[4 * t + 2] = excl + c0 + c1; first[4 * t + 3] = excl + c0 + c1 + c2;
+        for (int o = 32; o > 0; o >>= 1) {
+            work += __shfl_xor(work, o, 64);
+            const uint32_t other = (uint32_t)__shfl_xor((int)kmin, o, 64);
+            kmin = other < kmin ? other : kmin;
+        }
+        // work of the keys up to and including each of this lane's (keys are ordered expensive first)
+        float mine = 0.0f, upto[4];
+        for (int j = 0; j < 4; ++j) { mine += (float)c[j] * exp2f((float)(255 - (4 * t + j)) * 0.125f); upto[j] = mine; }
+        float before = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(before, o, 64);
+            if (t >= o) before += up;
+        }
+        before -= mine;
+        const float per_wave = work / (float)(n_waves > 0 ? n_waves : 1);
+        // what the chip can do in the time the slowest sixteenth of the most expensive tile will take (0.64 of that tile),
+        // at the 60 % to which waves of such different lengths can be packed
+        const float budget = budget_frac * (float)n_waves * exp2f((float)(255 - (int)(kmin < 256u ? kmin : 255u)) * 0.125f);
+        uint32_t plain = 0, split = 0;
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t k = (uint32_t)(4 * t + j);
+            // sixteen waves at 0.64 of the tile's time each: ten times the tile's work, nine more than it costs whole
+            const bool s16 = allow_split && k - kmin < split_keys && exp2f((float)(255 - (int)k) * 0.125f) > 2.0f * per_wave &&
+                             work + 9.0f * (before + upto[j]) <= budget;
+            m[j] = s16 ? 16u : 1u;
+            plain += c[j]; split += c[j] * m[j];
+        }
+        uint32_t incl_p = plain, incl_s = split;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up_p = __shfl_up(incl_p, o, 64), up_s = __shfl_up(incl_s, o, 64);
+            if (t >= o) { incl_p += up_p; incl_s += up_s; }
+        }
+        const uint32_t total_s = (uint32_t)__shfl((int)incl_s, 63, 64);
+        const bool fits = total_s <= capacity;                     // otherwise nothing is split this time
+        uint32_t at = fits ? incl_s - split : incl_p - plain;
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t mj = fits ? m[j] : 1u;
+            first[4 * t + j] = at; mult[4 * t + j] = mj;
+            at += c[j] * mj;
+        }
+        if (blockIdx.x == 0 && t == 63) *n_entries = fits ? total_s : (uint32_t)n;
     }
     __syncthreads();
     if (i < n) {
-        const uint32_t p = packed[i];
-        order[first[p >> 24] + (p & 0xffffffu)] = (uint32_t)i;
+        const uint32_t p = packed[i], k = p >> 24, m = mult[k];
+        const uint32_t at = first[k] + (p & 0xffffffu) * m;
+        if (m == 1u) order[at] = (uint32_t)i;
+        else for (uint32_t j = 0; j < m; ++j) order[at + j] = (uint32_t)i | ((j + 1u) << 24);
     }
 }
-// n < 2^24.  hist: 256 words, zero on entry.
-hipError_t launch_order_tiles(const uint32_t* cost, uint32_t* packed, uint32_t* hist, uint32_t* order, int n, hipStream_t stream) {
+// n < 2^24.  cost, state, packed: n words each.  hist: 256 words, zero on entry.  order: `capacity` entries; n_entries receives how many were written (n, or
+// more when allow_split let some tiles be listed as sixteenths).
+hipError_t launch_order_tiles(uint32_t* cost, uint32_t* state, uint32_t* packed, uint32_t* hist, uint32_t* order, int n, bool allow_split, int n_waves,
+                              float budget_frac, int split_keys, size_t capacity, unsigned long long* n_entries, hipStream_t stream) {
     const dim3 grid((unsigned)((n + 1023) / 1024)), block(1024);
-    hipLaunchKernelGGL(tile_keys_kernel, grid, block, 0, stream, cost, packed, hist, n);
-    hipLaunchKernelGGL(tile_order_kernel, grid, block, 0, stream, packed, (const uint32_t*)hist, order, n);
+    hipLaunchKernelGGL(tile_keys_kernel, grid, block, 0, stream, cost, state, packed, hist, n);
+    hipLaunchKernelGGL(tile_order_kernel, grid, block, 0, stream, (const uint32_t*)packed, (const uint32_t*)hist, order, n, allow_split ? 1 : 0, n_waves,
+                       budget_frac, (uint32_t)split_keys, (uint32_t)std::min<size_t>(capacity, 0xffffffffu), n_entries);
     return hipGetLastError();
 }
 
@@ -1515,12 +1675,22 @@ static hipError_t launch_global_mode(const SceneDev& S, const FrameDev& F, hipSt
     return hipGetLastError();
 }
 
+// Workgroups and waves of a launch of the persistent kernel.  With a tile order the list may hold sixteen entries for
+// a tile, so even a frame of few tiles gets every CU.
+int resident_blocks(int n_tiles, int n_cus, int threads, bool ordered) {
+    const int waves = std::max(64, std::min(kResidentThreads, threads / 64 * 64)) / 64;
+    const long long entries = ordered ? 16ll * n_tiles : (long long)n_tiles;
+    return (int)std::max<long long>(1, std::min<long long>(n_cus, (entries + waves - 1) / waves));
+}
+int resident_waves(int n_tiles, int n_cus, int threads, bool ordered) {
+    return resident_blocks(n_tiles, n_cus, threads, ordered) * (std::max(64, std::min(kResidentThreads, threads / 64 * 64)) / 64);
+}
+
 template <int MODE>
 static hipError_t launch_resident_mode(const SceneDev& S, const FrameDev& F, int n_cus, int threads, hipStream_t stream) {
     const size_t lds = resident_lds_bytes(S.n_node_slots, S.n_tris, F.stack_entries);
+    const int blocks = resident_blocks(F.n_tiles, n_cus, threads, F.tile_order != nullptr);
     threads = std::max(64, std::min(kResidentThreads, threads / 64 * 64));
-    const int waves = threads / 64;
-    const int blocks = std::max(1, std::min(n_cus, (F.n_tiles + waves - 1) / waves));
     FrameDev Fq = F;
     Fq.n_queues = std::min(kTileQueues, blocks);          // every queue needs a workgroup of its own: nobody else drains it
     hipLaunchKernelGGL((render_tiles_resident<MODE>), dim3((unsigned)blocks), dim3((unsigned)threads), lds, stream, S, Fq);

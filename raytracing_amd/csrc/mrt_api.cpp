@@ -25,7 +25,9 @@ hipError_t launch_eye_relative(const SceneDev& S, const float eye[3], float grou
 hipError_t launch_eye_groups(const SceneDev& S, const float eye[3], float group_pad, uint4* out, hipStream_t stream);
 hipError_t prepare_render_kernels();
 hipError_t launch_depth_view(const SceneDev& S, const FrameDev& F, hipStream_t stream);
-hipError_t launch_order_tiles(const uint32_t* cost, uint32_t* packed, uint32_t* hist, uint32_t* order, int n, hipStream_t stream);
+hipError_t launch_order_tiles(uint32_t* cost, uint32_t* state, uint32_t* packed, uint32_t* hist, uint32_t* order, int n, bool allow_split, int n_waves,
+                              float budget_frac, int split_keys, size_t capacity, unsigned long long* n_entries, hipStream_t stream);
+int resident_waves(int n_tiles, int n_cus, int threads, bool ordered);
 size_t resident_lds_bytes(int n_node_slots, int n_tris, int stack_entries);
 hipError_t launch_trace_packets(const SceneDev& S, int n_packets, const float* O, const float* D, const float* rD,
                                 float* t, int32_t* tri, float* u, float* v, unsigned long long* flag, hipStream_t stream);
@@ -83,7 +85,7 @@ struct DevBuf {
 // ---------------------------------------------------------------------------------------------
 constexpr int kNoAllocMaxTiles = MRT_NOALLOC_MAX_TILES;
 constexpr size_t kScratchCounterBytes = (size_t)kCounterSlots * sizeof(unsigned long long);
-constexpr size_t kScratchBytes = kScratchCounterBytes + 3 * (size_t)kNoAllocMaxTiles * sizeof(uint32_t);
+constexpr size_t kScratchBytes = kScratchCounterBytes + 4 * (size_t)kNoAllocMaxTiles * sizeof(uint32_t);
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
 namespace {
@@ -147,7 +149,7 @@ struct mrt_ctx {
     DevBuf<unsigned long long> d_counters;
     // per-tile clocks of the last persistent-kernel launch and the tile order derived from them;
     // cost_shape identifies the launch they belong to (0: none)
-    DevBuf<uint32_t> d_tile_cost, d_tile_packed, d_tile_order;
+    DevBuf<uint32_t> d_tile_cost, d_tile_packed, d_tile_order, d_tile_state;
     unsigned long long cost_shape = 0;
     // last_stream is only ever COMPARED with the stream of the next launch (it may be a caller's stream that no
     // longer exists); everything that has to wait for the last launch waits on last_done.
@@ -155,6 +157,8 @@ struct mrt_ctx {
     hipEvent_t last_done = nullptr;   // recorded after every frame launch: the context's counters and queues are shared,
     bool launched = false;            // so a launch on another stream first waits for the previous one
     int last_n_lights = 0;                         // lights of the last launch (the shadow-ray counter is relative to it)
+    int last_n_tiles = 0;                          // tiles of the last launch, and whether its queues handed out an order list
+    bool last_ordered = false;
     unsigned long long* last_counters = nullptr;   // counter block the last launch used (the context's own or the GPU's scratch)
     unsigned char* scratch_dev = nullptr;          // this GPU's copy of the scratch array (mrt_render_device_noalloc)
     // ray arrays of the operator-level entry points, kept between calls (grown on demand)
@@ -247,7 +251,7 @@ struct RowShare { int part = 0, n_parts = 1, block = 1, compact = 0; };
 // (or reuse) the context's own; otherwise they hold `capacity` tiles and nothing is allocated.
 struct FrameScratch {
     unsigned long long* counters = nullptr;
-    uint32_t *tile_cost = nullptr, *tile_packed = nullptr, *tile_order = nullptr;
+    uint32_t *tile_cost = nullptr, *tile_packed = nullptr, *tile_order = nullptr, *tile_state = nullptr;
     unsigned long long* shape = nullptr;      // where the identity of the launch that wrote tile_cost is kept
     int capacity = 0;
 };
@@ -300,6 +304,8 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
         c->launched = true;
         c->last_counters = F.counters;
         c->last_n_lights = 0;
+        c->last_n_tiles = F.n_tiles;
+        c->last_ordered = false;
         return MRT_OK;
     }
     bool resident = c->resident && mode == (int)MRT_MODE_RECURSIVE && c->scene.n_objects == 0;
@@ -310,21 +316,31 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
         const unsigned long long shape = ((unsigned long long)F.n_tiles << 24) ^ ((unsigned long long)F.tile_y0 << 12) ^
                                          ((unsigned long long)g << 8) ^ ((unsigned long long)F.part << 4) ^
                                          ((unsigned long long)F.n_parts << 16) ^ ((unsigned long long)F.part_block << 40) ^ ((unsigned long long)mode << 1) ^ 1ull;
-        uint32_t *cost, *packed, *order;
+        uint32_t *cost, *packed, *order, *state;
         unsigned long long* last_shape;
         unsigned long long key = shape;
+        size_t order_capacity;
         if (fixed) {
-            cost = fixed->tile_cost; packed = fixed->tile_packed; order = fixed->tile_order; last_shape = fixed->shape;
+            cost = fixed->tile_cost; packed = fixed->tile_packed; order = fixed->tile_order; state = fixed->tile_state; last_shape = fixed->shape;
+            order_capacity = (size_t)fixed->capacity;
             key ^= (unsigned long long)(uintptr_t)c * 0x9e3779b97f4a7c15ull ^ ((unsigned long long)c->scene_serial << 52);   // the scratch is shared by every context on the GPU
             key |= 1ull;
         } else {
             MRT_HIP(c, c->d_tile_cost.ensure((size_t)F.n_tiles));
             MRT_HIP(c, c->d_tile_packed.ensure((size_t)F.n_tiles));
-            MRT_HIP(c, c->d_tile_order.ensure((size_t)F.n_tiles));
-            cost = c->d_tile_cost.p; packed = c->d_tile_packed.p; order = c->d_tile_order.p; last_shape = &c->cost_shape;
+            order_capacity = (size_t)F.n_tiles + kOrderExtra;
+            MRT_HIP(c, c->d_tile_order.ensure(order_capacity));
+            MRT_HIP(c, c->d_tile_state.ensure((size_t)F.n_tiles));
+            cost = c->d_tile_cost.p; packed = c->d_tile_packed.p; order = c->d_tile_order.p; state = c->d_tile_state.p; last_shape = &c->cost_shape;
         }
         if (*last_shape == key) {
-            MRT_HIP(c, launch_order_tiles(cost, packed, reinterpret_cast<uint32_t*>(F.counters + kOrderHistBase), order, F.n_tiles, stream));
+            // expensive tiles of the recursive shader may be listed as sixteenths (kernels.hip: tile_order_kernel); the packet
+            // traversal needs all 64 rays of a tile in one wave, and a sample grid is resolved across the tile's lanes
+            const bool allow_split = mode == (int)MRT_MODE_RECURSIVE && g == 1;
+            const int threads = env_int("MRT_RESIDENT_THREADS", kResidentThreads);
+            MRT_HIP(c, launch_order_tiles(cost, state, packed, reinterpret_cast<uint32_t*>(F.counters + kOrderHistBase), order, F.n_tiles, allow_split,
+                                          resident_waves(F.n_tiles, c->n_cus, threads, true), (float)env_int("MRT_SPLIT_BUDGET", 50) * 0.01f, env_int("MRT_SPLIT_KEYS", 6), order_capacity,
+                                          F.counters + kOrderCountSlot, stream));
             F.tile_order = order;
         }
         F.tile_cost = cost;
@@ -361,6 +377,8 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
     c->launched = true;
     c->last_counters = F.counters;
     c->last_n_lights = c->scene.n_lights;
+    c->last_n_tiles = F.n_tiles;
+    c->last_ordered = F.tile_order != nullptr;
     return MRT_OK;
 }
 
@@ -418,7 +436,7 @@ void mrt_destroy(mrt_ctx* c) {
     c->d_triG.release(); c->d_triM.release(); c->d_eye_nodes.release(); c->d_eye_tri.release(); c->d_eye_g.release(); c->d_triG_eye.release();
     c->d_tex.release(); c->d_texels.release(); c->d_pal.release(); c->d_objects.release();
     c->d_fb.release(); c->d_ids.release(); c->d_counters.release();
-    c->d_tile_cost.release(); c->d_tile_packed.release(); c->d_tile_order.release();
+    c->d_tile_cost.release(); c->d_tile_packed.release(); c->d_tile_order.release(); c->d_tile_state.release();
     raster_release(c->raster);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
@@ -762,6 +780,7 @@ int mrt_render_device_noalloc(mrt_ctx* c, const float cam[16], uint32_t flags, i
     fs.tile_cost = reinterpret_cast<uint32_t*>(c->scratch_dev + kScratchCounterBytes);
     fs.tile_packed = fs.tile_cost + kNoAllocMaxTiles;
     fs.tile_order = fs.tile_packed + kNoAllocMaxTiles;
+    fs.tile_state = fs.tile_order + kNoAllocMaxTiles;
     fs.capacity = kNoAllocMaxTiles;
     fs.shape = &g_scratch_shape[c->device];
     return render_common(c, cam, flags, y_begin, y_end, (uint32_t*)fb_dev, pitch_px, (int32_t*)hit_ids_dev, (hipStream_t)stream, nullptr, &fs);
@@ -913,6 +932,21 @@ int mrt_get_ray_counts(mrt_ctx* c, uint64_t out[4]) {
     out[3] = hits;
     const unsigned long long wd = tmp[5];
     if (wd != 0) return fail(c, MRT_E_LIMIT, "a traversal loop exhausted its iteration budget (code " + std::to_string(wd) + ")");
+    return MRT_OK;
+}
+
+int mrt_get_tile_schedule(mrt_ctx* c, uint64_t out[2]) {
+    if (!c || !out) return MRT_E_ARG;
+    MRT_HIP(c, hipSetDevice(c->device));
+    out[0] = out[1] = 0;
+    if (!c->launched) return MRT_OK;
+    MRT_HIP(c, hipEventSynchronize(c->last_done));
+    out[0] = out[1] = (uint64_t)c->last_n_tiles;
+    if (c->last_ordered) {
+        unsigned long long v = 0;
+        MRT_HIP(c, hipMemcpy(&v, c->last_counters + kOrderCountSlot, sizeof v, hipMemcpyDeviceToHost));
+        out[1] = v;
+    }
     return MRT_OK;
 }
 

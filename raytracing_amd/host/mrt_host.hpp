@@ -509,6 +509,7 @@ public:
     }
     void Wait(int ticket) { check(mrt_render_wait(ctx_, ticket), "mrt_render_wait"); }
     void RayCounts(uint64_t out[4]) { check(mrt_get_ray_counts(ctx_, out), "mrt_get_ray_counts"); }
+    void TileSchedule(uint64_t out[2]) { check(mrt_get_tile_schedule(ctx_, out), "mrt_get_tile_schedule"); }
     mrt_ctx* Context() { return ctx_; }
 
 private:

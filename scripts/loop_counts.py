@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--spp-grid", type=int, default=1)
     ap.add_argument("--scene", default="maze", help="maze | maze+spheres (the two spheres of raytracer.cpp:404-412, lifted to y = 1.5) | "
                     "soup:N (the large-scene generator) | mixed:N (that soup in three meshes: opaque, mirror, mirror + glass)")
-    ap.add_argument("--pose", default="P0", help="P0 (identity) | P1 | soup (5,1,4) -> (0,0,-20)")
+    ap.add_argument("--pose", default="P0", help="P0 (identity) | P1 | soup (5,1,4) -> (0,0,-20) | inside (0,0.5,-23) -> (3,0,-30)")
     args = ap.parse_args()
     from raytracing_amd import binding
     binding.LIB_PATH = os.path.join(ROOT, "raytracing_amd", "libmrt_prof.so")
@@ -69,6 +69,9 @@ def main():
     elif args.pose == "soup":
         cam.set_position((5, 1, 4))
         cam.look_at((0, 0, -20))
+    elif args.pose == "inside":         # inside the soup's bounds: the recursive shader's root gate (raytracer.cpp:947) lets rays in
+        cam.set_position((0, 0.5, -23))
+        cam.look_at((3, 0, -30))
     for mode, name in ((0, "packet"), (1, "recursive")):
         rt.render_device(cam, fb.data_ptr(), args.w, mode=mode, spp_grid=args.spp_grid, stream=stream.cuda_stream)
         torch.cuda.synchronize()

@@ -19,14 +19,15 @@ def main():
     from raytracing_amd import Camera, Raytracer, scene_io
     L = binding.lib()
     L.mrt_debug_tile_costs.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-    w, h = 1920, 1080
+    w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
     scene = scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "maze.mrts"))
     rt = Raytracer(w, h, device=0)
     rt.build_bvh(scene)
     fb = torch.zeros((h, w), dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream()
     cam = Camera()
-    for _ in range(3):
+    frames = int(sys.argv[4]) if len(sys.argv) > 4 else 3     # 1: a frame in frame order, nothing split; from 2 on the tile order is active
+    for _ in range(frames):
         rt.render_device(cam, fb.data_ptr(), w, mode=mode, stream=stream.cuda_stream)
     torch.cuda.synchronize()
     n = (w // 8) * (h // 8)
@@ -36,10 +37,11 @@ def main():
     waves = 4096
     print("tiles %d  sum %.3g clocks  mean %.0f  median %.0f  p90 %.0f  p99 %.0f  max %.0f" %
           (got, c.sum(), c.mean(), np.median(c), np.percentile(c, 90), np.percentile(c, 99), c.max()))
+    print("ten most expensive:", " ".join("%d:%.0f" % (i, c[i]) for i in np.argsort(-c)[:10]))
     print("perfect balance over %d waves: %.0f clocks per wave; heaviest tile: %.0f clocks" % (waves, c.sum() / waves, c.max()))
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    np.save(os.path.join(out, "tile_costs_mode%d.npy" % mode), cost[:got])
+    np.save(os.path.join(out, "tile_costs_mode%d_%dx%d.npy" % (mode, w, h)), cost[:got])
     grid = c.reshape(h // 8, w // 8)
     rows = grid.mean(axis=1)
     print("mean cost per tile row (every 9th):", " ".join("%.0f" % r for r in rows[::9]))

@@ -595,6 +595,39 @@ def test_tile_order_from_previous_frame_changes_nothing(maze_scene, W, H):
     rt.close()
 
 
+@pytest.mark.parametrize("W,H", [(512, 512), (800, 600), (256, 144)])
+def test_expensive_tiles_in_sixteenths_change_nothing(maze_scene, maze_oracle, W, H):
+    """Small frames of the recursive shader: from the second frame of a view on, the most expensive tiles of the previous
+    frame are handed out as sixteen 2x2-pixel parts, every pixel of a part traced by a team of 16 lanes that share out the
+    triangles of each leaf (kernels.hip: render_tile, traverse_nearest).  mrt_get_tile_schedule shows that it happens;
+    pixels, hit ids and ray counts must be those of the frame rendered in frame order, and of the oracle."""
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(maze_scene)
+    n_tiles = (W // 8) * (H // 8)
+    for pose in (POSES[0], POSES[1], POSES[4]):
+        cam = pose_cam(pose)
+        base_fb, base_ids = rt.render(cam, mode=MODE_RECURSIVE, extra_flags=binding.FLAG_FRAME_ORDER)
+        assert rt.tile_schedule() == (n_tiles, n_tiles)
+        base_counts = rt.ray_counts()
+        parts = []
+        for _ in range(5):
+            fb, ids = rt.render(cam, mode=MODE_RECURSIVE)
+            tiles, handed = rt.tile_schedule()
+            assert tiles == n_tiles and handed >= tiles and (handed - tiles) % 15 == 0
+            parts.append((handed - tiles) // 15)
+            assert np.array_equal(ids, base_ids) and np.array_equal(fb, base_fb), "%s, frame with %d tiles in parts" % (pose[0], parts[-1])
+            assert rt.ray_counts() == base_counts
+        if pose[0] == "P0_identity":
+            assert parts[0] == 0 and max(parts[1:]) > 0, parts        # (the first frame of a view has no costs to go by)
+        want = maze_oracle.render(cam, W, H, mode=MODE_RECURSIVE)
+        assert np.array_equal(base_ids, want["ids"]) and colour_mismatch_fraction(base_fb, want["fb"]) <= 0.001
+    # the packet path and frames with a sample grid are never split
+    rt.render(pose_cam(POSES[0]), mode=MODE_PACKET)
+    rt.render(pose_cam(POSES[0]), mode=MODE_PACKET)
+    assert rt.tile_schedule() == (n_tiles, n_tiles)
+    rt.close()
+
+
 def test_submit_and_wait_keep_frames_in_flight(maze_scene):
     """mrt_render_submit / mrt_render_wait: four frames queued at once land in their page-locked frames
     identical to what the synchronous mrt_render gives; a fifth is refused until one has been waited for."""
