@@ -179,17 +179,21 @@ int mrt_render_device(mrt_ctx* ctx, const float cam_to_world[16], uint32_t flags
                       int y_begin, int y_end, void* fb_dev, int pitch_px,
                       void* hit_ids_dev, void* stream);
 
-/* mrt_render_device for callers that cannot allocate device memory: code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference.  Same arguments,
+/* mrt_render_device for callers that cannot allocate device memory: tight serving loops, harnesses that forbid
+ * hipMalloc.  (NOT for recording into a HIP graph: which kernels a frame needs is decided on the host at every call --
+ * the eye-relative arrays are rewritten only when the eye or the scene has changed, the tile order is made only when
+ * the previous launch had the same shape -- and the call records, and may wait on, an event of the context; a recorded
+ * graph would replay one call's decisions for every later frame.)  It has NO counterpart in the reference.  Same arguments,
  * same kernels, same pixels; but where mrt_render_device keeps the frame's counter block (tile queues,
  * ray counters, watchdog word) and the per-tile cost / order arrays of the tile scheduler in buffers it
- * allocates on demand, this call keeps them in a fixed array of the library's code object (about 3.2 MB
+ * allocates on demand, this call keeps them in a fixed array of the library's code object (about 4.2 MB
  * on every GPU the library runs on, until the process ends) and calls no hipMalloc / hipFree or other
  * allocating routine.  A launch of more than MRT_NOALLOC_MAX_TILES 8x8 tiles (traced size, i.e. times g*g
  * with MRT_SPP_GRID(g)) is refused with MRT_E_LIMIT.  ALL contexts on one GPU share the array and it keeps
  * the last call's contents: the call clears what must start at zero itself, but two such calls that
  * overlap in time on one GPU (different contexts or different processes' streams of one process) race --
- * order them on one stream or with events.  mrt_get_ray_counts after it reads the same array. */
+ * order them on one stream or with events.  mrt_get_ray_counts and mrt_get_tile_schedule after it read the same array,
+ * and fail with MRT_E_STATE when another context has rendered into it in between. */
 #define MRT_NOALLOC_MAX_TILES 262144
 int mrt_render_device_noalloc(mrt_ctx* ctx, const float cam_to_world[16], uint32_t flags,
                               int y_begin, int y_end, void* fb_dev, int pitch_px,

@@ -1424,7 +1424,9 @@ int ora_render(Context* c, const float* cam16, int W, int H, int mode, int spp_g
         for (int y = y_begin; y < y_end; ++y) for (int x = 0; x < W; ++x) maxDepth = std::max(maxDepth, (int)fb[x + (size_t)y * pitch]);
         for (int y = y_begin; y < y_end; ++y) for (int x = 0; x < W; ++x) {
             const int depth = (int)fb[x + (size_t)y * pitch];
-            const vec4 col = vclamp(vec4{1, (float)depth / maxDepth, 1.0f - (float)depth / maxDepth, 0}, 0.0f, 1.0f);
+            // (a scene without triangles has depth 0 everywhere: the reference would divide 0 by 0, shown here as 0)
+            const float part = maxDepth > 0 ? (float)depth / maxDepth : 0.0f;
+            const vec4 col = vclamp(vec4{1, part, 1.0f - part, 0}, 0.0f, 1.0f);
             fb[x + (size_t)y * pitch] = vec_to_pixel(col);
         }
     }

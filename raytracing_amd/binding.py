@@ -240,8 +240,14 @@ class Raytracer:
         self._check(self.L.mrt_set_lights(self.h, _p(a), len(a)), "mrt_set_lights")
 
     def set_objects(self, objects):
-        """Raytracer::m_Objects: rows of 13 floats {kind (0 sphere, 1 plane), pos.xyz, radius | dist, diffuse.xyzw, refl, refr, rindex}."""
-        a = np.ascontiguousarray(objects, np.float32).reshape(-1, 13)
+        """Raytracer::m_Objects: an (n, 12) array of {kind (0 sphere, 1 plane), pos.xyz, radius | dist, diffuse.xyzw, refl, refr,
+        rindex}; a thirteenth column is tolerated and ignored (rows used to be padded)."""
+        a = np.asarray(objects, np.float32)
+        if a.size == 0:
+            a = a.reshape(0, 12)
+        if a.ndim != 2 or a.shape[1] not in (12, 13):
+            raise ValueError("objects must be an (n, 12) array (or (n, 13) with an unused last column), got shape %s" % (a.shape,))
+        a = np.ascontiguousarray(a)
         arr = (_Object * max(1, len(a)))()
         for i, r in enumerate(a):
             arr[i] = _Object(int(r[0]), (C.c_float * 3)(*r[1:4]), float(r[4]), (C.c_float * 4)(*r[5:9]), float(r[9]), float(r[10]), float(r[11]))

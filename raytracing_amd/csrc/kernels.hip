@@ -1360,7 +1360,9 @@ __global__ __launch_bounds__(256) void depth_colour_kernel(uint32_t* fb, int pit
     const int x = (int)(blockIdx.x * 256 + threadIdx.x), y = (int)blockIdx.y;
     if (x >= W || y >= H) return;
     const int maxDepth = (int)*max_depth, depth = (int)fb[(size_t)y * pitch + x];
-    fb[(size_t)y * pitch + x] = vec_to_pixel(clamp01(f4{1.0f, (float)depth / maxDepth, 1.0f - (float)depth / maxDepth, 0.0f}));
+    // (a scene without triangles: every count is 0, and 0 of 0 is shown as 0 rather than evaluated)
+    const float part = maxDepth > 0 ? (float)depth / maxDepth : 0.0f;
+    fb[(size_t)y * pitch + x] = vec_to_pixel(clamp01(f4{1.0f, part, 1.0f - part, 0.0f}));
 }
 hipError_t launch_depth_view(const SceneDev& S, const FrameDev& F, hipStream_t stream) {
     if (F.n_tiles <= 0) return hipSuccess;

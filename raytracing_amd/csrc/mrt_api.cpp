@@ -93,6 +93,10 @@ constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mutex;
 unsigned char* g_scratch_ptr[kMaxDevices] = {};            // device address of `scratch` on each GPU, once known
 unsigned long long g_scratch_shape[kMaxDevices] = {};       // launch the tile costs in a GPU's scratch belong to (0: none)
+// who launched into a GPU's scratch last: context and that context's count of such launches.  The counters of a launch
+// (ray counts, watchdog word) can only be read back while the stamp still names it.  All three arrays: g_scratch_mutex.
+struct ScratchOwner { const void* ctx = nullptr; unsigned long long serial = 0; };
+ScratchOwner g_scratch_owner[kMaxDevices];
 
 // With `device` current: the address of this GPU's copy of the scratch array (looked up once per device).
 hipError_t scratch_of(int device, unsigned char** out) {
@@ -161,6 +165,7 @@ struct mrt_ctx {
     bool last_ordered = false;
     unsigned long long* last_counters = nullptr;   // counter block the last launch used (the context's own or the GPU's scratch)
     unsigned char* scratch_dev = nullptr;          // this GPU's copy of the scratch array (mrt_render_device_noalloc)
+    unsigned long long noalloc_serial = 0;         // this context's launches into it
     // ray arrays of the operator-level entry points, kept between calls (grown on demand)
     DevBuf<float> d_rayO, d_rayD, d_rayR, d_rayT, d_rayU, d_rayV;
     DevBuf<int32_t> d_rayTri;
@@ -333,7 +338,15 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
             MRT_HIP(c, c->d_tile_state.ensure((size_t)F.n_tiles));
             cost = c->d_tile_cost.p; packed = c->d_tile_packed.p; order = c->d_tile_order.p; state = c->d_tile_state.p; last_shape = &c->cost_shape;
         }
-        if (*last_shape == key) {
+        bool same_shape;
+        {
+            // the scratch's slot is shared by every context (and host thread) on the GPU
+            std::unique_lock<std::mutex> lock(g_scratch_mutex, std::defer_lock);
+            if (fixed) lock.lock();
+            same_shape = *last_shape == key;
+            *last_shape = key;
+        }
+        if (same_shape) {
             // expensive tiles of the recursive shader may be listed as sixteenths (kernels.hip: tile_order_kernel); the packet
             // traversal needs all 64 rays of a tile in one wave, and a sample grid is resolved across the tile's lanes
             const bool allow_split = mode == (int)MRT_MODE_RECURSIVE && g == 1;
@@ -344,7 +357,6 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
             F.tile_order = order;
         }
         F.tile_cost = cost;
-        *last_shape = key;
     }
     if (mode == (int)MRT_MODE_PACKET && !resident) {
         // Frames of one context run one after the other (last_done above), so the arrays are rewritten only when
@@ -430,6 +442,14 @@ void mrt_destroy(mrt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     if (c->launched) { (void)hipEventSynchronize(c->last_done); }     // the last frame may be on a caller's stream
+    {
+        // a context created later may get this one's address: nothing in the shared scratch may pass for its own
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (c->device >= 0 && c->device < kMaxDevices) {
+            g_scratch_shape[c->device] = 0;
+            if (g_scratch_owner[c->device].ctx == c) g_scratch_owner[c->device] = ScratchOwner{};
+        }
+    }
     c->d_rayO.release(); c->d_rayD.release(); c->d_rayR.release(); c->d_rayT.release(); c->d_rayU.release(); c->d_rayV.release();
     c->d_rayTri.release(); c->d_rayFlag.release();
     c->d_nodes.release(); c->d_triA.release(); c->d_triB.release(); c->d_triC.release(); c->d_attr.release(); c->d_lights.release();
@@ -489,6 +509,10 @@ int mrt_set_objects(mrt_ctx* c, const mrt_object* objects, int n) {
     MRT_HIP(c, hipStreamSynchronize(c->stream));
     refresh_scene_view(c);
     c->cost_shape = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        g_scratch_shape[c->device] = 0;        // (tile costs in the shared scratch may be this context's: they go with the old list)
+    }
     return MRT_OK;
 }
 
@@ -783,6 +807,10 @@ int mrt_render_device_noalloc(mrt_ctx* c, const float cam[16], uint32_t flags, i
     fs.tile_state = fs.tile_order + kNoAllocMaxTiles;
     fs.capacity = kNoAllocMaxTiles;
     fs.shape = &g_scratch_shape[c->device];
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        g_scratch_owner[c->device] = ScratchOwner{c, ++c->noalloc_serial};
+    }
     return render_common(c, cam, flags, y_begin, y_end, (uint32_t*)fb_dev, pitch_px, (int32_t*)hit_ids_dev, (hipStream_t)stream, nullptr, &fs);
 }
 
@@ -912,10 +940,22 @@ int mrt_render_wait(mrt_ctx* c, int ticket) {
     return MRT_OK;
 }
 
+// The counters of the context's last launch can be read: they are its own, or the GPU's shared scratch array and no other
+// launch has gone into that since.
+static int counters_still_ours(mrt_ctx* c) {
+    if (!c->last_counters || c->last_counters != reinterpret_cast<unsigned long long*>(c->scratch_dev)) return MRT_OK;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    const ScratchOwner& o = g_scratch_owner[c->device];
+    if (o.ctx == c && o.serial == c->noalloc_serial) return MRT_OK;
+    return fail(c, MRT_E_STATE, "the counters of this context's last frame were in the GPU's shared scratch array (mrt_render_device_noalloc) and "
+                                "another context has rendered into it since");
+}
+
 int mrt_get_ray_counts(mrt_ctx* c, uint64_t out[4]) {
     if (!c || !out) return MRT_E_ARG;
     MRT_HIP(c, hipSetDevice(c->device));
     if (c->launched) MRT_HIP(c, hipEventSynchronize(c->last_done));
+    if (int rc = counters_still_ours(c)) return rc;
     std::vector<unsigned long long> tmp(kCounterSlots);
     MRT_HIP(c, hipMemcpy(tmp.data(), c->last_counters ? c->last_counters : c->d_counters.p, kCounterSlots * sizeof(unsigned long long),
                          hipMemcpyDeviceToHost));
@@ -943,6 +983,7 @@ int mrt_get_tile_schedule(mrt_ctx* c, uint64_t out[2]) {
     MRT_HIP(c, hipEventSynchronize(c->last_done));
     out[0] = out[1] = (uint64_t)c->last_n_tiles;
     if (c->last_ordered) {
+        if (int rc = counters_still_ours(c)) return rc;
         unsigned long long v = 0;
         MRT_HIP(c, hipMemcpy(&v, c->last_counters + kOrderCountSlot, sizeof v, hipMemcpyDeviceToHost));
         out[1] = v;

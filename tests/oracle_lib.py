@@ -172,8 +172,14 @@ class Oracle:
 
     # ---- rendering ----
     def set_objects(self, objects):
-        """Analytic primitives: rows of 13 floats {kind (0 sphere, 1 plane), pos.xyz, radius | dist, diffuse.xyzw, refl, refr, rindex, 0}."""
-        a = np.ascontiguousarray(objects, np.float32).reshape(-1, 13)
+        """Analytic primitives: rows of 12 floats {kind (0 sphere, 1 plane), pos.xyz, radius | dist, diffuse.xyzw, refl, refr, rindex} (a 13th column is ignored)."""
+        a = np.asarray(objects, np.float32)
+        a = a.reshape(0, 13) if a.size == 0 else a
+        if a.ndim != 2 or a.shape[1] not in (12, 13):
+            raise ValueError("objects must be (n, 12) or (n, 13)")
+        if a.shape[1] == 12:
+            a = np.concatenate([a, np.zeros((len(a), 1), np.float32)], axis=1)
+        a = np.ascontiguousarray(a)
         self.L.ora_set_objects.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         self.L.ora_set_objects(self.h, _p(a), len(a))
 

@@ -61,6 +61,13 @@ def test_bvh_depth_view_on_a_soup_and_an_empty_scene():
         ref = ora.render(cam, 192, 128, mode=MODE_BVH_DEPTH)
         assert np.array_equal(ids, ref["ids"]) and np.array_equal(fb, ref["fb"])
     rt.close()
+    # no triangles at all: every pixel enters 0 nodes, and 0 of 0 is shown like 0 of anything (A = 1, R = 0, G = 1, B = 0)
+    scene["meshes"] = []
+    rt, ora = _pair(scene, 64, 64)
+    fb, ids = rt.render(oracle_lib.IDENTITY, mode=MODE_BVH_DEPTH)
+    ref = ora.render(oracle_lib.IDENTITY, 64, 64, mode=MODE_BVH_DEPTH)
+    assert (fb == 0xFF00FF00).all() and np.array_equal(fb, ref["fb"]) and (ids == -1).all() and np.array_equal(ids, ref["ids"])
+    rt.close()
 
 
 @pytest.mark.parametrize("objects", [REFERENCE_SPHERES, np.concatenate([REFERENCE_SPHERES, PLANE])], ids=["two spheres", "spheres and plane"])
@@ -91,6 +98,14 @@ def test_spheres_and_planes_match_oracle(maze_scene, objects):
         bad = REFERENCE_SPHERES.copy()
         bad[0, 0] = 7
         rt.set_objects(bad)
+    # rows of the twelve documented fields work like rows with the historical thirteenth (unused) column
+    rt.set_objects(objects[:, :12])
+    ora.set_objects(objects)
+    fb, ids = rt.render(pose_cam(POSES[1]), mode=MODE_PACKET)
+    ref = ora.render(pose_cam(POSES[1]), W, H, mode=MODE_PACKET)
+    assert np.array_equal(ids, ref["ids"]) and np.array_equal(fb, ref["fb"])
+    with pytest.raises(ValueError):
+        rt.set_objects(np.zeros((2, 11), np.float32))
     rt.close()
 
 

@@ -55,6 +55,17 @@ def test_noalloc_entry_point_equals_allocating_one(maze_scene):
         big.render_device_noalloc(cam_a, fb.data_ptr(), 640, mode=MODE_RECURSIVE, stream=stream)
     torch.cuda.synchronize()
     assert np.array_equal(fb.cpu().numpy().view(np.uint32), want)
+    # the counters of a frame live in the shared array too: once another context has rendered into it they are gone, and
+    # asking for them says so instead of reporting the other context's rays
+    counts = big.ray_counts()
+    fbs = torch.zeros((128, 256), dtype=torch.int32, device="cuda:0")
+    small.render_device_noalloc(cam_b, fbs.data_ptr(), 256, mode=MODE_PACKET, stream=stream)
+    torch.cuda.synchronize()
+    with pytest.raises(MrtError, match="another context"):
+        big.ray_counts()
+    assert small.ray_counts()["primary"] == 256 * 128
+    big.render_device_noalloc(cam_a, fb.data_ptr(), 640, mode=MODE_RECURSIVE, stream=stream)
+    assert big.ray_counts() == counts
     big.close()
     small.close()
 
