@@ -18,6 +18,7 @@
 #include "device_scene.h"
 #include "mrt_math.h"
 #include "raster.h"
+#include "refit.h"
 
 namespace mrt {
 hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool resident, int n_cus, int resident_threads, hipStream_t stream);
@@ -184,6 +185,8 @@ struct mrt_ctx {
     int next_ticket = 0;
     // rasterizer
     RasterState raster;
+    // the tree's shape on the device, for mrt_scene_refit
+    RefitState refit;
 };
 
 namespace {
@@ -458,6 +461,7 @@ void mrt_destroy(mrt_ctx* c) {
     c->d_fb.release(); c->d_ids.release(); c->d_counters.release();
     c->d_tile_cost.release(); c->d_tile_packed.release(); c->d_tile_order.release(); c->d_tile_state.release();
     raster_release(c->raster);
+    refit_release(c->refit);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (auto& f : c->flight) {
@@ -488,7 +492,7 @@ int mrt_set_lights(mrt_ctx* c, const float* pos_rgba7, int n) {
     return MRT_OK;
 }
 
-enum class TreeSource { Reference, Lbvh, Refit };
+enum class TreeSource { Reference, Lbvh };
 static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures, TreeSource source);
 
 int mrt_set_objects(mrt_ctx* c, const mrt_object* objects, int n) {
@@ -524,58 +528,58 @@ int mrt_scene_upload_lbvh(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, cons
     return scene_upload(c, meshes, n_meshes, textures, n_textures, TreeSource::Lbvh);
 }
 
+static int scene_refit(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes);
 int mrt_scene_refit(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes) {
-    return scene_upload(c, meshes, n_meshes, nullptr, 0, TreeSource::Refit);
+    return scene_refit(c, meshes, n_meshes);
 }
 
-// New bounds for the tree the context holds, bottom-up, after its triangles have moved: a leaf's box spans its
-// triangles' vertices, an inner node's box its two children's.  Which triangles a leaf holds and how the nodes
-// hang together stays as it is.
-static void refit_bounds(HostBVH& B) {
-    if (B.n_tris == 0) return;
-    std::vector<uint32_t> order;             // nodes in pre-order: walked backwards, children come before their parent
-    order.reserve((size_t)B.pool_ptr + 1);
-    std::vector<uint32_t> todo{0u};
-    while (!todo.empty()) {
-        const uint32_t n = todo.back();
-        todo.pop_back();
-        order.push_back(n);
-        if (B.count[n] == 0) { todo.push_back(B.first[n]); todo.push_back(B.first[n] + 1); }
+// mrt_scene_refit: the tree stays, everything that depends on vertex positions is recomputed on the device (refit.hip)
+// from the rasterizer's vertex arrays, which are refreshed first.  The triangles' vertex indices are those of the upload.
+static int scene_refit(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes) {
+    if (!c) return MRT_E_ARG;
+    if (!c->has_scene) return fail(c, MRT_E_STATE, "mrt_scene_refit needs a scene: call mrt_scene_upload first");
+    if (n_meshes < 0 || (n_meshes > 0 && !meshes)) return fail(c, MRT_E_ARG, "meshes is null");
+    // the old geometry stays in place if the new one is refused: everything is checked before anything is written
+    size_t tris = 0;
+    for (int m = 0; m < n_meshes; ++m) {
+        const mrt_mesh& M = meshes[m];
+        if (M.tris < 0 || M.verts < 0) return fail(c, MRT_E_ARG, "negative vertex/triangle count");
+        if (M.tris > 0 && (!M.pos || !M.uv || !M.tri_normal || !M.tri)) return fail(c, MRT_E_ARG, "mesh array is null");
+        tris += (size_t)M.tris;
     }
-    // leaves are independent of each other
-    parallel_for(order.size(), [&](size_t b, size_t e) {
-        for (size_t i = b; i < e; ++i) {
-            const uint32_t n = order[i];
-            if (B.count[n] == 0) continue;
-            f3 lo = {1e30f, 1e30f, 1e30f}, hi = {-1e30f, -1e30f, -1e30f};       // raytracer.h:258-262 starts its boxes there
-            for (uint32_t k = B.first[n]; k < B.first[n] + B.count[n]; ++k) {
-                const HostTri& t = B.tris[B.idx[k]];
-                for (const f3& p : {t.p0, t.p1, t.p2}) {
-                    lo = {gmin(lo.x, p.x), gmin(lo.y, p.y), gmin(lo.z, p.z)};
-                    hi = {gmax(hi.x, p.x), gmax(hi.y, p.y), gmax(hi.z, p.z)};
-                }
-            }
-            B.nmin[n] = lo; B.nmax[n] = hi;
-        }
-    });
-    for (size_t i = order.size(); i-- > 0;) {
-        const uint32_t n = order[i];
-        if (B.count[n] != 0) continue;
-        const uint32_t l = B.first[n], r = l + 1;
-        B.nmin[n] = {gmin(B.nmin[l].x, B.nmin[r].x), gmin(B.nmin[l].y, B.nmin[r].y), gmin(B.nmin[l].z, B.nmin[r].z)};
-        B.nmax[n] = {gmax(B.nmax[l].x, B.nmax[r].x), gmax(B.nmax[l].y, B.nmax[r].y), gmax(B.nmax[l].z, B.nmax[r].z)};
+    if (tris != c->bvh.tris.size())
+        return fail(c, MRT_E_ARG, "mrt_scene_refit: " + std::to_string(tris) + " triangles, the uploaded scene has " +
+                                  std::to_string(c->bvh.tris.size()) + " (a refit keeps the tree: same meshes, same triangle counts)");
+    if ((size_t)n_meshes != c->raster.meshes.size()) return fail(c, MRT_E_ARG, "mrt_scene_refit: another number of meshes than the uploaded scene has");
+    for (int m = 0; m < n_meshes; ++m)
+        if (meshes[m].verts != c->raster.meshes[m].verts || meshes[m].tris != c->raster.meshes[m].tris)
+            return fail(c, MRT_E_ARG, "mrt_scene_refit: mesh " + std::to_string(m) + " has another number of vertices or triangles than at upload "
+                                      "(a refit keeps the tree: same meshes, same triangle counts)");
+    MRT_HIP(c, hipSetDevice(c->device));
+    if (c->launched) MRT_HIP(c, hipEventSynchronize(c->last_done));      // a frame in flight may still read the old arrays
+    std::string err;
+    c->has_scene = false;
+    if (int rc = raster_refit(c->raster, meshes, n_meshes, c->stream, err)) return fail(c, rc, err);
+    float largest = 0.0f;
+    bool coords_ok = true;
+    MRT_HIP(c, refit_run(c->refit, c->raster.d_pos, c->raster.d_uv, c->raster.d_N, c->raster.d_tri, c->d_nodes.p, c->d_triA.p, c->d_triB.p, c->d_triC.p,
+                         c->d_triM.p, c->has_groups ? c->d_triG.p : nullptr, c->d_attr.p, c->stream, &largest, &coords_ok));
+    if (tris == 0) MRT_HIP(c, hipStreamSynchronize(c->stream));
+    if (tris > 0) {
+        c->group_pad = largest * 0x1p-12f;
+        c->scene.coords_ok = coords_ok ? 1 : 0;
     }
+    c->has_scene = true;
+    c->cost_shape = 0;          // tile costs of the old geometry say little about the new one
+    ++c->scene_serial;          // (the eye-relative copies of the old arrays are stale)
+    return MRT_OK;
 }
 
 static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures, TreeSource source) {
     if (!c) return MRT_E_ARG;
-    const bool lbvh = source == TreeSource::Lbvh, refit = source == TreeSource::Refit;
-    if (refit) {
-        if (!c->has_scene) return fail(c, MRT_E_STATE, "mrt_scene_refit needs a scene: call mrt_scene_upload first");
-        n_textures = c->scene.n_textures;          // the textures stay as they are
-    }
-    if (!refit && (n_textures < 0 || (n_textures > 0 && !textures))) return fail(c, MRT_E_ARG, "bad texture array");
-    for (int i = 0; i < n_textures && !refit; ++i)
+    const bool lbvh = source == TreeSource::Lbvh;
+    if (n_textures < 0 || (n_textures > 0 && !textures)) return fail(c, MRT_E_ARG, "bad texture array");
+    for (int i = 0; i < n_textures; ++i)
         if (!textures[i].indices || !textures[i].palettes || textures[i].width <= 0 || textures[i].height <= 0)
             return fail(c, MRT_E_ARG, "bad texture");
     MRT_HIP(c, hipSetDevice(c->device));
@@ -588,29 +592,15 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
         fprintf(stderr, "mrt_scene_upload: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
     };
-    if (refit) {
-        // the context stays usable with its old geometry if the new one is refused
-        std::vector<HostTri> moved;
-        if (!flatten_meshes(meshes, n_meshes, n_textures, true, moved, err)) return fail(c, MRT_E_ARG, err);
-        if (moved.size() != c->bvh.tris.size())
-            return fail(c, MRT_E_ARG, "mrt_scene_refit: " + std::to_string(moved.size()) + " triangles, the uploaded scene has " +
-                                      std::to_string(c->bvh.tris.size()) + " (a refit keeps the tree: same meshes, same triangle counts)");
-        c->has_scene = false;
-        c->bvh.tris.swap(moved);
-        stage("flatten");
-        refit_bounds(c->bvh);
-    } else {
-        c->has_scene = false;
-        if (!flatten_meshes(meshes, n_meshes, n_textures, true, c->bvh.tris, err)) return fail(c, MRT_E_ARG, err);
-        stage("flatten");
-    }
-    if (refit) {
-    } else if (lbvh && !c->bvh.tris.empty()) {
+    c->has_scene = false;
+    if (!flatten_meshes(meshes, n_meshes, n_textures, true, c->bvh.tris, err)) return fail(c, MRT_E_ARG, err);
+    stage("flatten");
+    if (lbvh && !c->bvh.tris.empty()) {
         if (!build_lbvh_device(c->bvh, c->stream, err)) return fail(c, MRT_E_HIP, err);
     } else {
         build_bvh(c->bvh);
     }
-    stage(refit ? "bounds (refit)" : lbvh ? "tree (GPU)" : "tree (host)");
+    stage(lbvh ? "tree (GPU)" : "tree (host)");
     const HostBVH& B = c->bvh;
     if (B.max_depth + 2 > kStackDepth) return fail(c, MRT_E_LIMIT, "BVH deeper than the traversal stack (62 levels)");
     if (B.pool_ptr >= (1u << 26)) return fail(c, MRT_E_LIMIT, "too many BVH nodes for the packet work list encoding");
@@ -722,10 +712,10 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
             }
         });
     }
-    std::vector<int4> tex(refit ? 0 : n_textures);
+    std::vector<int4> tex(n_textures);
     std::vector<uint8_t> texels;
-    std::vector<uint32_t> pal(refit ? 0 : (size_t)n_textures * 32 * 256);
-    for (int i = 0; i < n_textures && !refit; ++i) {
+    std::vector<uint32_t> pal((size_t)n_textures * 32 * 256);
+    for (int i = 0; i < n_textures; ++i) {
         const size_t n = (size_t)textures[i].width * textures[i].height;
         tex[i] = make_int4((int)texels.size(), textures[i].width, textures[i].height, 0);
         texels.insert(texels.end(), textures[i].indices, textures[i].indices + n);
@@ -740,11 +730,9 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     MRT_HIP(c, c->d_triM.upload(triM, c->stream));
     if (c->has_groups) MRT_HIP(c, c->d_triG.upload(triG, c->stream));
     MRT_HIP(c, c->d_attr.upload(attr, c->stream));
-    if (!refit) {
-        MRT_HIP(c, c->d_tex.upload(tex, c->stream));
-        MRT_HIP(c, c->d_texels.upload(texels, c->stream));
-        MRT_HIP(c, c->d_pal.upload(pal, c->stream));
-    }
+    MRT_HIP(c, c->d_tex.upload(tex, c->stream));
+    MRT_HIP(c, c->d_texels.upload(texels, c->stream));
+    MRT_HIP(c, c->d_pal.upload(pal, c->stream));
     MRT_HIP(c, c->d_lights.upload(c->lights, c->stream));
     MRT_HIP(c, c->d_eye_nodes.ensure(std::max<size_t>(1, 2 * slots)));
     MRT_HIP(c, c->d_eye_tri.ensure(std::max<size_t>(4, 4 * (size_t)B.n_tris)));
@@ -754,6 +742,8 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     if (int rc = raster_upload(c->raster, meshes, n_meshes, c->stream, err)) return fail(c, rc, err);
     MRT_HIP(c, hipStreamSynchronize(c->stream));
     stage("rasterizer arrays");
+    MRT_HIP(c, refit_prepare(c->refit, c->bvh, c->stream));
+    stage("tree shape for refits");
     refresh_scene_view(c);
     c->scene.n_textures = n_textures;
     c->scene.n_node_slots = (int)slots;

@@ -67,6 +67,9 @@ struct RasterState {
 };
 
 int raster_upload(RasterState& R, const mrt_mesh* meshes, int n_meshes, hipStream_t stream, std::string& err);
+// The same meshes with moved vertices (same vertex and triangle counts, checked by the caller): positions, uvs and face
+// normals are copied over the ones on the device, mesh bounds are recomputed; nothing is allocated.  Asynchronous on `stream`.
+int raster_refit(RasterState& R, const mrt_mesh* meshes, int n_meshes, hipStream_t stream, std::string& err);
 int raster_render(RasterState& R, const RasterTextures& tx, int W, int H, const float cam[16], uint32_t* fb, int pitch_px,
                   float* zbuf, int32_t* tri_ids, bool device_out, hipStream_t stream, std::string& err);
 void raster_release(RasterState& R);

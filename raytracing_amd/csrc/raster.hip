@@ -27,6 +27,7 @@
 #include "host_parallel.h"
 
 #include <algorithm>
+#include <mutex>
 
 namespace mrt {
 
@@ -760,6 +761,36 @@ int raster_upload(RasterState& R, const mrt_mesh* meshes, int n_meshes, hipStrea
     RASTER_HIP(hipMemcpyAsync(R.d_N, N.data(), N.size() * 4, hipMemcpyHostToDevice, stream));
     RASTER_HIP(hipMemcpyAsync(R.d_tri, tri.data(), tri.size() * 4, hipMemcpyHostToDevice, stream));
     RASTER_HIP(hipStreamSynchronize(stream));      // the staging vectors go out of scope
+    return MRT_OK;
+}
+
+int raster_refit(RasterState& R, const mrt_mesh* meshes, int n_meshes, hipStream_t stream, std::string& err) {
+    if ((size_t)n_meshes != R.meshes.size()) { err = "raster_refit: another number of meshes"; return MRT_E_ARG; }
+    for (int m = 0; m < n_meshes; ++m) {
+        const mrt_mesh& M = meshes[m];
+        RasterMeshHost& h = R.meshes[m];
+        if (M.verts != h.verts || M.tris != h.tris) { err = "raster_refit: a mesh has changed its size"; return MRT_E_ARG; }
+        if (M.verts == 0) continue;
+        // scenedata.cpp:258-263, a few threads for a large mesh
+        std::mutex mu;
+        f3 lo = {1e30f, 1e30f, 1e30f}, hi = {-1e30f, -1e30f, -1e30f};
+        parallel_for((size_t)M.verts, [&](size_t b, size_t e) {
+            f3 l = {1e30f, 1e30f, 1e30f}, u = {-1e30f, -1e30f, -1e30f};
+            for (size_t i = b; i < e; ++i) {
+                const float* p = M.pos + 3 * i;
+                l = {gmin(l.x, p[0]), gmin(l.y, p[1]), gmin(l.z, p[2])};
+                u = {gmax(u.x, p[0]), gmax(u.y, p[1]), gmax(u.z, p[2])};
+            }
+            std::lock_guard<std::mutex> lock(mu);
+            lo = {gmin(lo.x, l.x), gmin(lo.y, l.y), gmin(lo.z, l.z)};
+            hi = {gmax(hi.x, u.x), gmax(hi.y, u.y), gmax(hi.z, u.z)};
+        }, (size_t)1 << 16);
+        h.bounds[0] = lo; h.bounds[1] = hi;
+        if (R.n_tris == 0) continue;
+        RASTER_HIP(hipMemcpyAsync(R.d_pos + 3 * (size_t)h.vert_off, M.pos, 12 * (size_t)M.verts, hipMemcpyHostToDevice, stream));
+        RASTER_HIP(hipMemcpyAsync(R.d_uv + 2 * (size_t)h.vert_off, M.uv, 8 * (size_t)M.verts, hipMemcpyHostToDevice, stream));
+        if (M.tris > 0) RASTER_HIP(hipMemcpyAsync(R.d_N + 3 * (size_t)h.tri_off, M.tri_normal, 12 * (size_t)M.tris, hipMemcpyHostToDevice, stream));
+    }
     return MRT_OK;
 }
 
