@@ -31,7 +31,10 @@ Rank 0 prints one JSON line.  Besides the contract's keys it carries
                     previous frame's costs; a camera at rest is the best case of that);
   c3_1m_tris_4k -- synthetic 1,000,000-triangle soup at 3840x2160, packet path (scene in global
                    memory, divergent traversal);
-  c5_raster_1m_4k -- the rasterizer path on the same soup, device-resident frame.
+  c5_raster_1m_4k -- the rasterizer path on the same soup, device-resident frame;
+  c2_800x600    -- the headline scene and shader at the reference's own window size (and at 512x512);
+  gpu_built_tree -- the headline workload on the tree built on the GPU instead of the reference's;
+  c3_recursive  -- the soup through the recursive shader (background only, as in the reference).
 Every one of them carries a `roofline` object.  The reference algorithm's test counts of the configurations the
 CPU oracle cannot render inside a benchmark run (8K / 16 spp, 1 M triangles) are read from
 tests/golden/full_size.json, which tests/golden/make_full_size_goldens.py made with the oracle.
@@ -180,6 +183,7 @@ class Workload:
         if self.world > 1:
             dist.barrier()
         sync()
+        self.events = []               # (a workload may be run more than once)
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step(timed=True)
@@ -212,14 +216,25 @@ class Workload:
 
 
 def cpu_model():
+    """The host CPU's name: /proc/cpuinfo's, or lscpu's when that one is terse (some hosts only say "AMD EPYC")."""
+    name = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
             for line in f:
                 if line.startswith("model name"):
-                    return line.split(":", 1)[1].strip()
+                    name = line.split(":", 1)[1].strip()
+                    break
     except OSError:
         pass
-    return "unknown"
+    if len(name.split()) < 3:
+        try:
+            import subprocess
+            for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=5).stdout.splitlines():
+                if line.startswith("Model name") and len(line.split(":", 1)[1].split()) > len(name.split()):
+                    name = line.split(":", 1)[1].strip()
+        except (OSError, subprocess.SubprocessError):
+            pass
+    return name
 
 
 def host_cpus():
@@ -450,6 +465,51 @@ def main():
     if world == 1:
         del head
     if not args.no_extra and world == 1:
+        # Small frames of the recursive shader: the reference's own window (game.h:3-4) and its 512x512 configuration.  Below
+        # a million pixels a frame used to take as long as its most expensive tile; those tiles are now handed out in sixteenths.
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        small = {}
+        for sw, sh in ((800, 600), (512, 512)):
+            wl = Workload("c2small", scene, sw, sh, MODE_RECURSIVE, 1, cam, rank, world, torch, dist)
+            rs = wl.run(args.steps, args.warmup)
+            tiles, handed = wl.rt.tile_schedule()
+            o = oracle_lib.Oracle()
+            o.add_scene(scene)
+            o.build_bvh()
+            o.set_threads(threads)
+            want = o.render(cam, sw, sh, mode=MODE_RECURSIVE, want_ids=False, want_counters=True)
+            k = want["counters"]
+            got = wl.frame()
+            a8 = got.view(np.uint8).reshape(-1, 4).astype(np.int16)
+            b8 = want["fb"].view(np.uint8).reshape(-1, 4).astype(np.int16)
+            assert k["primary_rays"] + k["shadow_rays"] + k["secondary_rays"] == rs["rays_per_step"]
+            assert float((np.abs(a8 - b8).max(axis=1) > 1).mean()) <= 0.001
+            small["%dx%d" % (sw, sh)] = {"value": round(rs["mrays_per_s"], 3), "unit": "Mrays/s", "ms_per_step": round(rs["ms_per_step"], 5),
+                                         "kernel_ms": round(rs["kernel_ms"], 5), "rays_per_frame": rs["rays_per_step"],
+                                         "tiles": tiles, "tiles_in_sixteenths": (handed - tiles) // 15,
+                                         "pixels_different_from_oracle": int((a8 != b8).any(axis=1).sum()),
+                                         "roofline": valu_roofline(flops_of(k), rs["kernel_ms"], "render_tiles_resident<recursive>")}
+            del wl
+        out["c2_800x600"] = dict(small["800x600"], workload="the headline scene and shader at the reference's own window size, 800x600 (game.h:3-4); "
+                                 "`also_512x512`: the same at 512x512", also_512x512=small["512x512"])
+        # The headline workload on the tree built on the GPU (mrt_scene_upload_lbvh) instead of the reference's own: never `value`,
+        # because which triangle is named on an exact distance tie follows the tree (one frame in ninety of a random-pose campaign
+        # had a pixel that differed); this frame is compared with the oracle's like every other.
+        from raytracing_amd import Raytracer
+        rt_gpu = Raytracer(W, H, device=torch.cuda.current_device())
+        t0 = time.perf_counter()
+        rt_gpu.build_bvh(scene, lbvh=True)
+        build_ms = (time.perf_counter() - t0) * 1e3
+        wl = Workload("c2gputree", scene, W, H, MODE_RECURSIVE, 1, cam, rank, world, torch, dist, rt=rt_gpu)
+        rg = wl.run(args.steps, args.warmup)
+        out["gpu_built_tree"] = {"workload": "the headline workload on the tree mrt_scene_upload_lbvh builds on the GPU (clustering by surface area) instead of the "
+                                             "reference's tree; same rays, same nearest hits, exact distance ties may name the other triangle",
+                                 "value": round(rg["mrays_per_s"], 3), "unit": "Mrays/s", "ms_per_step": round(rg["ms_per_step"], 5),
+                                 "kernel_ms": round(rg["kernel_ms"], 5), "rays_per_frame": rg["rays_per_step"], "tree_build_and_upload_ms": round(build_ms, 3),
+                                 "frame_hash_equals_oracle": _fbsum(wl.frame()) == golden["c2_maze_1080p_recursive"]["fbsum"]}
+        del wl, rt_gpu
+    if not args.no_extra and world == 1:
         c4 = Workload("c4", scene, 7680, 4320, MODE_PACKET, 4, cam, rank, world, torch, dist, split="rows")
         r4 = c4.run(max(2, min(args.steps, 5)), 1)
         out["c4_8k_16spp"] = {"workload": c4_workload, "scaling": "strong", "value": round(r4["mrays_per_s"], 3), "unit": "Mrays/s",
@@ -530,6 +590,30 @@ def main():
                                                                "bytes_model": "32 B x (packet node fetches + single-ray box tests) + 36 B x (packet leaf triangles + single-ray "
                                                                               "triangle tests) + 4 B per pixel: bytes the reference algorithm asks for, nearly all served by caches "
                                                                               "(compare `traffic`)"}, **traffic_of("c3"))}
+        # the recursive shader on the same scene: with the eye outside the scene's bounds the root test of BVH::Traverse, which is
+        # handed the direction where it expects the reciprocal (raytracer.cpp:947), turns every ray away -- the reference renders
+        # this camera as background only, and so does the frame here (checked against the oracle's checksum); its cost is ray
+        # generation, one box test per ray and the pixel
+        c3.mode = MODE_RECURSIVE
+        r3r = c3.run(max(2, min(args.steps, 10)), 2)
+        g3r = golden["c3_soup1m_4k_recursive"]
+        assert _fbsum(c3.frame()) == g3r["fbsum"] and g3r["counters"]["primary_rays"] == r3r["rays_per_step"]
+        out["c3_recursive"] = {"workload": "the same soup and camera, recursive shader: every primary ray ends at the root test of BVH::Traverse (the eye lies "
+                                           "outside the scene's bounds and the test is handed D for 1/D, raytracer.cpp:947), as in the reference",
+                               "value": round(r3r["mrays_per_s"], 3), "unit": "Mrays/s", "ms_per_step": round(r3r["ms_per_step"], 4),
+                               "kernel_ms": round(r3r["kernel_ms"], 4), "rays_per_frame": r3r["rays_per_step"], "frame_hash_equals_oracle": True,
+                               "roofline": valu_roofline(flops_of(g3r["counters"]), r3r["kernel_ms"], "render_tiles_global<recursive>",
+                                                         counts="tests/golden/full_size.json (oracle, offline)")}
+        c3.mode = MODE_PACKET
+        # moving geometry: mrt_scene_refit keeps the tree and recomputes boxes, triangle records and attributes on the device
+        t0 = time.perf_counter()
+        c3.rt.refit(soup)
+        refit_ms = (time.perf_counter() - t0) * 1e3
+        c3.step()
+        assert _fbsum(c3.frame()) == g3["fbsum"]
+        out["c3_1m_tris_4k"]["scene_refit_ms"] = round(refit_ms, 3)
+        out["c3_1m_tris_4k"]["scene_refit_what"] = ("wall time of one mrt_scene_refit call on this scene (72 MB of vertices over PCIe from pageable memory included); "
+                                                    "the frame after it equals the oracle's")
         # the rasterizer on the same scene, frame resident in device memory: kernels only
         fbr = torch.zeros((2160, 3840), dtype=torch.int32, device="cuda")
         st = torch.cuda.current_stream()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random-pose parity campaign: GPU frames (both shaders, through the C ABI) against the CPU oracle for many random
 cameras in and around the default scene, random light positions, random sample grids.  Prints a summary line;
-exit status 1 on the first mismatch beyond the parity bar.  usage: parity_fuzz.py [poses] [seed]"""
+exit status 1 on the first mismatch beyond the parity bar.  usage: parity_fuzz.py [--gpu-tree] [poses] [seed]"""
 import os
 import sys
 
@@ -68,6 +68,9 @@ def soups(n_scenes, seed):
 
 
 def main():
+    gpu_tree = "--gpu-tree" in sys.argv      # the clustered tree built on the GPU instead of the reference's: differences are counted, not fatal
+    if gpu_tree:
+        sys.argv.remove("--gpu-tree")
     if len(sys.argv) > 1 and sys.argv[1] == "--soups":
         return soups(int(sys.argv[2]) if len(sys.argv) > 2 else 20, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     n_poses = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -83,8 +86,9 @@ def main():
     sizes = [(256, 192), (320, 200), (128, 128), (512, 64)]
     rts = {s: Raytracer(s[0], s[1], device=0) for s in sizes}
     for rt in rts.values():
-        rt.build_bvh(scene)
+        rt.build_bvh(scene, lbvh=gpu_tree)
     worst = 0.0
+    rays = id_diffs = px_diffs = frames_off = 0
     for i in range(n_poses):
         W, H = sizes[i % len(sizes)]
         rt = rts[(W, H)]
@@ -102,6 +106,14 @@ def main():
         for mode in (0, 1):
             fb, ids = rt.render(cam, mode=mode, spp_grid=g)
             ref = ora.render(cam, W, H, mode=mode, spp_grid=g)
+            if gpu_tree:
+                rays += ids.size
+                d = int((ids != ref["ids"]).sum())
+                a = fb.view(np.uint8).reshape(-1, 4).astype(np.int16)
+                b = ref["fb"].view(np.uint8).reshape(-1, 4).astype(np.int16)
+                e = int((np.abs(a - b).max(axis=1) > 1).sum()) if mode == 1 else int((fb != ref["fb"]).sum())
+                id_diffs += d; px_diffs += e; frames_off += (d > 0 or e > 0)
+                continue
             if not np.array_equal(ids, ref["ids"]):
                 print("pose %d mode %d: %d hit ids differ (pos %s target %s)" % (i, mode, int((ids != ref["ids"]).sum()), pos, target))
                 return 1
@@ -113,6 +125,10 @@ def main():
                 print("pose %d mode %d: pixels differ (%.5f beyond 1/255; pos %s target %s)" % (i, mode, frac, pos, target))
                 return 1
             c = rt.ray_counts()
+    if gpu_tree:
+        print("parity_fuzz with the GPU-built tree: %d poses x 2 shaders, %d primary rays: %d hit ids and %d pixels (packet: at all, recursive: beyond 1/255) "
+              "differ from the oracle's, in %d frames" % (n_poses, rays, id_diffs, px_diffs, frames_off))
+        return 0
     print("parity_fuzz: %d poses x 2 shaders: hit ids identical, packet pixels identical, worst recursive fraction beyond 1/255: %.6f" % (n_poses, worst))
     return 0
 
