@@ -13,6 +13,11 @@
 //             triC[k] = {p0.z, bits(triangle id)}      (raytracer.cpp:289-290)
 //           The edges come first: the first 24 bytes decide whether the triangle faces away from a
 //           ray, which dismisses about half of all tests before the rest is read.
+//           Inside a leaf of kGroupMinLeaf or more triangles the slots are NOT in the reference's order: they are
+//           arranged so that neighbours in the array are neighbours in space (mrt_api.cpp: arrange_long_leaves), and
+//   place : per triangle ID {the triangle's place in the reference's order, the first place of its leaf}: settles what
+//           the order of the tests used to settle -- of two triangles of ONE leaf hit at exactly the same distance the
+//           one with the lower place is kept (kernels.hip: Tie).
 //   triM  : the triangle arrays once more as ONE record of 3 float4 per leaf-order slot, {triA, triB, {triC, 0, 0}}:
 //           the traversals in which all lanes test the same triangle (packet leaves, shadow rays) of the
 //           global-memory kernels read a triangle through one address instead of three.
@@ -46,6 +51,7 @@ struct SceneDev {
     const float2* triC;
     const uint4* triG;
     const float4* triM;
+    const uint2* place;      // per triangle id: {its place in the tree's own leaf order, the first place of its leaf}
     const float4* attr;
     const int4* tex;
     const uint8_t* texels;

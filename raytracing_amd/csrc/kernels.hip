@@ -105,6 +105,7 @@ struct SceneGlobalT {
     const v4f* nodes; const v4f* triA; const v4f* triB; const v2f* triC;
     const v4u* triG;      // group boxes (device_scene.h)
     const v4f* triM;      // the same triangles as one 48-byte record each (device_scene.h): one address per test
+    const uint2* place;   // triangle id -> {place in the tree's own leaf order, first place of its leaf} (device_scene.h)
     static constexpr bool kMergedTris = true;
     __device__ __forceinline__ bool has_groups() const { return G; }
     __device__ __forceinline__ v4u group(uint32_t g) const { return triG[g]; }
@@ -143,6 +144,7 @@ struct SceneLds {
     static constexpr bool kShadowGroups = true;
     MRT_LDS const v4f* nodes; MRT_LDS const v4f* triA; MRT_LDS const v4f* triB; MRT_LDS const v2f* triC;
     MRT_LDS const v4u* triG; bool groups;
+    const uint2* place;   // (global memory: read only when two hits are equally far)
     static constexpr bool kMergedTris = false;
     __device__ __forceinline__ bool has_groups() const { return groups; }
     __device__ __forceinline__ v4u group(uint32_t g) const { return triG[g]; }
@@ -252,9 +254,24 @@ __device__ __forceinline__ bool slab_pair_shadow_interval(v4f l0, v4f l1, v4f r0
     return (leftN || l_no) && (rightN || r_no);
 }
 
+// Two triangles hit at exactly the same distance.  The reference tests the triangles of a leaf in the order of its
+// index array and keeps a hit only if it is strictly nearer (raytracer.cpp:1336-1344, 1452-1461): of two equally far
+// ones the one that comes FIRST in the leaf is kept, and a hit as far as one kept from an earlier leaf is dropped.
+// The device arrays hold the triangles of a long leaf in another order (device_scene.h), so the rule is applied by
+// name: place[id] = {the triangle's place in the reference's order, the first place of its leaf}.
+// place == nullptr: only "any hit" is asked.
+struct Tie {
+    const uint2* place;
+};
+__device__ __forceinline__ bool tie_goes_to(const Tie& tie, uint32_t id, int kept) {
+    if (!tie.place || kept < 0) return false;
+    const uint2 mine = tie.place[id], theirs = tie.place[kept];
+    return mine.y == theirs.y && mine.x < theirs.x;
+}
+
 // Second half of the triangle test: from the determinant and the three numerators to the running hit.
 template <bool WAVE_REJECT>
-__device__ __forceinline__ void tri_decide(float det, float un, float vn, float tn, uint32_t id, float& t, Hit& h, Watch& wd) {
+__device__ __forceinline__ void tri_decide(float det, float un, float vn, float tn, uint32_t id, float& t, Hit& h, Watch& wd, const Tie& tie) {
     if (WAVE_REJECT) {
         constexpr float m = 1e-5f;      // far above the 2^-22 relative error of estimate * numerator
         const float rc = __builtin_amdgcn_rcpf(det);
@@ -278,7 +295,9 @@ __device__ __forceinline__ void tri_decide(float det, float un, float vn, float 
     live = live && !(v < 0 || u + v > 1);
     if (!__any(live)) return;
     const float T = tn * invDet;
-    live = live && !(T < 0.0f) && (T < t);
+    bool nearer = T < t;
+    if (live && T == t) nearer = tie_goes_to(tie, id, h.tri);
+    live = live && !(T < 0.0f) && nearer;
     t = live ? T : t;
     h.tri = live ? (int)id : h.tri;
     h.u = live ? u : h.u;
@@ -293,7 +312,7 @@ __device__ __forceinline__ void tri_decide(float det, float un, float vn, float 
 // issued only when some lane cannot be ruled out that way.
 // ---------------------------------------------------------------------------------------
 template <bool WAVE_REJECT>
-__device__ __forceinline__ void tri_test(v4f A, v4f B, v2f C, f3 O, f3 D, float& t, Hit& h, Watch& wd) {
+__device__ __forceinline__ void tri_test(v4f A, v4f B, v2f C, f3 O, f3 D, float& t, Hit& h, Watch& wd, const Tie& tie) {
     const f3 e1 = {A.x, A.y, A.z}, e2 = {A.w, B.x, B.y}, p0 = {B.z, B.w, C.x};
     const f3 pvec = cross(D, e2);
     const float det = dot(e1, pvec);
@@ -306,23 +325,23 @@ __device__ __forceinline__ void tri_test(v4f A, v4f B, v2f C, f3 O, f3 D, float&
     const f3 qvec = cross(tvec, e1);
     const float vn = dot(D, qvec);
     const float tn = dot(e2, qvec);
-    tri_decide<WAVE_REJECT>(det, un, vn, tn, __float_as_uint(C.y), t, h, wd);
+    tri_decide<WAVE_REJECT>(det, un, vn, tn, __float_as_uint(C.y), t, h, wd, tie);
 }
 
 // A triangle all calling lanes test together, read the way the scene's home allows: one record, or three arrays.
 template <class SC>
-__device__ __forceinline__ void tri_test_shared(const SC& sc, uint32_t k, f3 O, f3 D, float& t, Hit& h, Watch& wd) {
+__device__ __forceinline__ void tri_test_shared(const SC& sc, uint32_t k, f3 O, f3 D, float& t, Hit& h, Watch& wd, const Tie& tie) {
     if constexpr (SC::kMergedTris) {
         const v4f* rec = sc.triM + 3 * (size_t)k;
         const v4f C = rec[2];
-        tri_test<true>(rec[0], rec[1], v2f{C.x, C.y}, O, D, t, h, wd);
+        tri_test<true>(rec[0], rec[1], v2f{C.x, C.y}, O, D, t, h, wd, tie);
     } else {
-        tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
+        tri_test<true>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd, tie);
     }
 }
 
 // The same test for a ray that starts at the eye, from the frame's precomputed record (SceneGlobalEyeT: eyeTri).
-__device__ __forceinline__ void tri_test_eye(const v4f* rec, f3 D, float& t, Hit& h, Watch& wd) {
+__device__ __forceinline__ void tri_test_eye(const v4f* rec, f3 D, float& t, Hit& h, Watch& wd, const Tie& tie) {
     const v4f A = rec[0], B = rec[1];
     const f3 e1 = {A.x, A.y, A.z}, e2 = {A.w, B.x, B.y};
     const f3 pvec = cross(D, e2);
@@ -332,7 +351,7 @@ __device__ __forceinline__ void tri_test_eye(const v4f* rec, f3 D, float& t, Hit
     const v4f C = rec[2], E = rec[3];
     const float un = dot(f3{B.z, B.w, C.x}, pvec);
     const float vn = dot(D, f3{C.z, C.w, E.x});
-    tri_decide<true>(det, un, vn, C.y, __float_as_uint(E.y), t, h, wd);
+    tri_decide<true>(det, un, vn, C.y, __float_as_uint(E.y), t, h, wd, tie);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -473,17 +492,18 @@ __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f
         for (;;) {                             // visit(node = {first,count}, firstActive = i)
             if (count != 0) {
                 if (lane >= i) {
+                    const Tie tie{sc.place};
                     if (sc.has_groups() && count >= (uint32_t)MRT_GROUP_MIN) {
                         walk_leaf_by_groups<SC::kEyeRelative>(sc, first, count, O, rg, rg_ok, t, wd, [&](uint32_t k) {
                             MRT_TICK(wd, 10);
-                            if constexpr (SC::kEyeRelative) tri_test_eye(sc.eyeTri + 4 * (size_t)k, D, t, h, wd);
-                            else tri_test_shared(sc, k, O, D, t, h, wd);
+                            if constexpr (SC::kEyeRelative) tri_test_eye(sc.eyeTri + 4 * (size_t)k, D, t, h, wd, tie);
+                            else tri_test_shared(sc, k, O, D, t, h, wd, tie);
                             return false;
                         });
                     } else if constexpr (SC::kEyeRelative) {
                         for (uint32_t k = first; k < first + count; ++k) {
                             MRT_TICK(wd, 10);
-                            tri_test_eye(sc.eyeTri + 4 * (size_t)k, D, t, h, wd);
+                            tri_test_eye(sc.eyeTri + 4 * (size_t)k, D, t, h, wd, tie);
                         }
                     } else if constexpr (SC::kPrefetchLeaf) {
                         v4f A = sc.tri_a(first), B = sc.tri_b(first);
@@ -494,13 +514,13 @@ __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f
                             const uint32_t kn = k < last ? k + 1 : k;
                             const v4f An = sc.tri_a(kn), Bn = sc.tri_b(kn);
                             const v2f Cn = sc.tri_c(kn);
-                            tri_test<true>(A, B, C, O, D, t, h, wd);
+                            tri_test<true>(A, B, C, O, D, t, h, wd, tie);
                             A = An; B = Bn; C = Cn;
                         }
                     } else {
                         for (uint32_t k = first; k < first + count; ++k) {
                             MRT_TICK(wd, 10);
-                            tri_test_shared(sc, k, O, D, t, h, wd);
+                            tri_test_shared(sc, k, O, D, t, h, wd, tie);
                         }
                     }
                 }
@@ -627,15 +647,21 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
                 static_assert(MRT_LEAF_CHUNK == 16, "a team is the 16 lanes of a DPP row");
                 const float t_before = t;
                 const uint32_t j = (uint32_t)lane & 15u;
-                if (j < n_now) tri_test<false>(sc.tri_a(first + j), sc.tri_b(first + j), sc.tri_c(first + j), O, D, t, h, wd);
-                if (__any(t < t_before)) {          // a member that hit has shortened its t: strictly, as the reference's test demands
+                const int tri_before = h.tri;
+                if (j < n_now) tri_test<false>(sc.tri_a(first + j), sc.tri_b(first + j), sc.tri_c(first + j), O, D, t, h, wd, Tie{sc.place});
+                if (__any(h.tri != tri_before)) {   // a member has a new hit: nearer, or equally far and earlier in the reference's order
                     float tw = t;
-                    int jw = (int)j;
+                    // what decides between members: the distance, then the kept triangle's place in the reference's order
+                    // (a member without a new hit holds the old one: equal in all, and never better than a new one)
+                    int jw = h.tri >= 0 ? (int)sc.place[h.tri].x : 0x7fffffff;
                     team_min_step<0xB1>(tw, jw);     // quad_perm [1,0,3,2]
                     team_min_step<0x4E>(tw, jw);     // quad_perm [2,3,0,1]
                     team_min_step<0x141>(tw, jw);    // row_half_mirror
                     team_min_step<0x140>(tw, jw);    // row_mirror
-                    const int from = (lane & 48) | jw;          // the winner (a member whose t is unchanged holds the old hit: equal in all)
+                    // the members that hold the winning triangle are asked for it (they hold the same u and v: same arithmetic)
+                    const int mine = h.tri >= 0 ? (int)sc.place[h.tri].x : 0x7fffffff;
+                    const unsigned long long holders = (__ballot(t == tw && mine == jw) >> (lane & 48)) & 0xffffull;
+                    const int from = (lane & 48) | (__ffsll((long long)holders) - 1);
                     t = tw;
                     h.tri = __shfl(h.tri, from, 64); h.u = __shfl(h.u, from, 64); h.v = __shfl(h.v, from, 64);
                 }
@@ -654,7 +680,7 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
                 MRT_TICK(wd, 1);
                 const uint32_t k = first + (uint32_t)__builtin_ctz(todo);
                 todo &= todo - 1u;
-                tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
+                tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd, Tie{sc.place});
             }
             first += n_now; count -= n_now;
             if (count == 0) {
@@ -710,7 +736,7 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
                 // member j of a team tests triangles j, j + 16, ... of the leaf; one member's hit is the team's answer
                 for (uint32_t k0 = first; k0 < first + count; k0 += 16u) {
                     const uint32_t k = k0 + ((uint32_t)lane & 15u);
-                    if (((m >> lane) & 1ull) && k < first + count && h.tri < 0) tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
+                    if (((m >> lane) & 1ull) && k < first + count && h.tri < 0) tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd, Tie{nullptr});
                     const unsigned long long hits = __ballot(h.tri >= 0);
                     if ((hits >> (lane & 48)) & 0xffffull) h.tri = 0;
                     if (!__any(h.tri < 0 && ((m >> lane) & 1ull))) break;
@@ -719,7 +745,7 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
                 if (SC::kShadowGroups && sc.has_groups() && count >= (uint32_t)MRT_GROUP_MIN) {
                     walk_leaf_by_groups<false>(sc, first, count, O, R.r, r_ok, t, wd, [&](uint32_t k) {
                         MRT_TICK(wd, 5);
-                        if (h.tri < 0) tri_test_shared(sc, k, O, D, t, h, wd);
+                        if (h.tri < 0) tri_test_shared(sc, k, O, D, t, h, wd, Tie{nullptr});
                         return !__any(h.tri < 0);
                     });
                 } else if constexpr (SC::kPrefetchLeaf) {
@@ -731,14 +757,14 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
                         const uint32_t kn = k < last ? k + 1 : k;
                         const v4f An = sc.tri_a(kn), Bn = sc.tri_b(kn);
                         const v2f Cn = sc.tri_c(kn);
-                        if (h.tri < 0) tri_test<true>(A, B, C, O, D, t, h, wd);
+                        if (h.tri < 0) tri_test<true>(A, B, C, O, D, t, h, wd, Tie{nullptr});
                         if (!__any(h.tri < 0)) break;
                         A = An; B = Bn; C = Cn;
                     }
                 } else {
                     for (uint32_t k = first; k < first + count; ++k) {
                         MRT_TICK(wd, 5);
-                        if (h.tri < 0) tri_test_shared(sc, k, O, D, t, h, wd);
+                        if (h.tri < 0) tri_test_shared(sc, k, O, D, t, h, wd, Tie{nullptr});
                         if (!__any(h.tri < 0)) break;
                     }
                 }
@@ -1218,7 +1244,7 @@ __device__ __forceinline__ int traverse_depth(const SC& sc, int n_tris, f3 O, f3
                 ++depth;
             } else take_next = true;
         } else {
-            for (uint32_t k = first; k < first + count; ++k) tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd);
+            for (uint32_t k = first; k < first + count; ++k) tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd, Tie{sc.place});
             take_next = true;
         }
         if (take_next) {
@@ -1238,7 +1264,7 @@ template <bool G>
 __device__ __forceinline__ SceneGlobalT<G> global_scene(const SceneDev& S) {
     return SceneGlobalT<G>{reinterpret_cast<const v4f*>(S.nodes), reinterpret_cast<const v4f*>(S.triA),
                        reinterpret_cast<const v4f*>(S.triB), reinterpret_cast<const v2f*>(S.triC),
-                       reinterpret_cast<const v4u*>(S.triG), reinterpret_cast<const v4f*>(S.triM)};
+                       reinterpret_cast<const v4u*>(S.triG), reinterpret_cast<const v4f*>(S.triM), S.place};
 }
 
 // Scene in global memory: one 64-thread workgroup (one wave) per tile.  SD = stack entries.
@@ -1415,7 +1441,7 @@ __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_t
         }
     }
     __syncthreads();
-    const SceneLds sc{l_nodes, l_a, l_b, l_c, l_g, S.triG != nullptr};
+    const SceneLds sc{l_nodes, l_a, l_b, l_c, l_g, S.triG != nullptr, S.place};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #ifdef MRT_LOOP_COUNTS
     const unsigned long long t_ready = __builtin_readcyclecounter();

@@ -128,6 +128,7 @@ struct mrt_ctx {
     DevBuf<float2> d_triC;
     DevBuf<uint4> d_triG;
     DevBuf<float4> d_triM;
+    DevBuf<uint2> d_place;      // per triangle id: its place in the tree's own leaf order and its leaf's first place (device_scene.h: place)
     bool has_groups = false;
     // nodes and triangles relative to the eye of the last packet-path frame (kernels.hip: SceneGlobalEyeT), sized at
     // scene upload; eye_key = the eye position and scene_serial they were made for
@@ -206,6 +207,7 @@ void refresh_scene_view(mrt_ctx* c) {
     S.nodes = c->d_nodes.p; S.triA = c->d_triA.p; S.triB = c->d_triB.p; S.triC = c->d_triC.p; S.attr = c->d_attr.p;
     S.triG = c->has_groups ? c->d_triG.p : nullptr;
     S.triM = c->d_triM.p;
+    S.place = c->d_place.p;
     S.tex = c->d_tex.p; S.texels = c->d_texels.p; S.pal = c->d_pal.p;
     S.lights = c->d_lights.p;
     S.objects = c->objects.empty() ? nullptr : c->d_objects.p;
@@ -456,7 +458,7 @@ void mrt_destroy(mrt_ctx* c) {
     c->d_rayO.release(); c->d_rayD.release(); c->d_rayR.release(); c->d_rayT.release(); c->d_rayU.release(); c->d_rayV.release();
     c->d_rayTri.release(); c->d_rayFlag.release();
     c->d_nodes.release(); c->d_triA.release(); c->d_triB.release(); c->d_triC.release(); c->d_attr.release(); c->d_lights.release();
-    c->d_triG.release(); c->d_triM.release(); c->d_eye_nodes.release(); c->d_eye_tri.release(); c->d_eye_g.release(); c->d_triG_eye.release();
+    c->d_triG.release(); c->d_triM.release(); c->d_place.release(); c->d_eye_nodes.release(); c->d_eye_tri.release(); c->d_eye_g.release(); c->d_triG_eye.release();
     c->d_tex.release(); c->d_texels.release(); c->d_pal.release(); c->d_objects.release();
     c->d_fb.release(); c->d_ids.release(); c->d_counters.release();
     c->d_tile_cost.release(); c->d_tile_packed.release(); c->d_tile_order.release(); c->d_tile_state.release();
@@ -575,6 +577,51 @@ static int scene_refit(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes) {
     return MRT_OK;
 }
 
+// The order of the triangles INSIDE a long leaf, as the device arrays hold them.  The reference tests a leaf's
+// triangles one after the other and keeps a hit only if it is strictly nearer (raytracer.cpp:1328-1346, 1445-1464): the
+// outcome is the nearest triangle, and of several at exactly the same distance the one that comes first in the leaf.
+// With that rule made explicit (kernels.hip: Tie -- on equal distance the triangle with the lower place in the
+// reference's order wins, if both belong to the leaf), the order in which a leaf is tested is free, and the traversals
+// skip groups of four consecutive triangles whose box a ray misses: so the triangles of a leaf of kGroupMinLeaf or more
+// are laid out by recursive bisection of their centroids (longest axis, halves ending on group boundaries), which makes
+// neighbours in the arrays neighbours in space and the groups' boxes small.  In the reference's own order the leaf is
+// sorted along one axis only and a group's box spans the leaf in the other two.
+static void arrange_long_leaves(const HostBVH& B, std::vector<uint32_t>& order) {
+    std::vector<uint32_t> leaves;
+    for (uint32_t i = 0; i <= B.pool_ptr && B.n_tris > 0; ++i)
+        if (i != 1 && i != 2 && B.count[i] >= (uint32_t)kGroupMinLeaf) leaves.push_back(i);
+    parallel_for(leaves.size(), [&](size_t lb, size_t le) {
+        std::vector<uint32_t> todo;
+        for (size_t li = lb; li < le; ++li) {
+            const uint32_t first = B.first[leaves[li]], end = first + B.count[leaves[li]];
+            todo.assign({first, end});
+            while (!todo.empty()) {
+                const uint32_t hi = todo.back(); todo.pop_back();
+                const uint32_t lo = todo.back(); todo.pop_back();
+                if (hi - lo <= 4u && (lo >> 2) == ((hi - 1u) >> 2)) continue;          // inside one group
+                f3 cl = {INFINITY, INFINITY, INFINITY}, ch = {-INFINITY, -INFINITY, -INFINITY};
+                for (uint32_t k = lo; k < hi; ++k) {
+                    const f3 c = B.tris[order[k]].centroid;
+                    cl = {std::min(cl.x, c.x), std::min(cl.y, c.y), std::min(cl.z, c.z)};
+                    ch = {std::max(ch.x, c.x), std::max(ch.y, c.y), std::max(ch.z, c.z)};
+                }
+                const float ex = ch.x - cl.x, ey = ch.y - cl.y, ez = ch.z - cl.z;
+                const int axis = (ex >= ey && ex >= ez) ? 0 : (ey >= ez ? 1 : 2);
+                auto key = [&](uint32_t id) { const f3 c = B.tris[id].centroid; return axis == 0 ? c.x : axis == 1 ? c.y : c.z; };
+                std::sort(order.begin() + lo, order.begin() + hi, [&](uint32_t a, uint32_t b) { const float ka = key(a), kb = key(b); return ka < kb || (ka == kb && a < b); });
+                // the halves end on a boundary of groups of four (of sixteen while the run is long): places are global, as the groups are
+                const uint32_t align = hi - lo > 32u ? 16u : 4u;
+                uint32_t mid = ((lo + hi) / 2u + align / 2u) / align * align;
+                if (mid <= lo || mid >= hi) mid = ((lo + hi) / 2u + 2u) / 4u * 4u;
+                if (mid <= lo || mid >= hi) mid = (lo + hi) / 2u;
+                if (mid <= lo || mid >= hi) continue;
+                todo.push_back(lo); todo.push_back(mid);
+                todo.push_back(mid); todo.push_back(hi);
+            }
+        }
+    }, 16);
+}
+
 static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures, TreeSource source) {
     if (!c) return MRT_E_ARG;
     const bool lbvh = source == TreeSource::Lbvh;
@@ -623,12 +670,21 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
         if (!ok) coords_all_ok = false;
     });
     const bool coords_ok = coords_all_ok;
+    // the device arrays' triangle order: the tree's leaf order (BVH::m_TriangleIdx), long leaves rearranged inside;
+    // place[id] = where triangle id stands in the tree's own order, which decides between equal distances
+    std::vector<uint32_t> order(B.idx.begin(), B.idx.begin() + B.n_tris);
+    std::vector<uint2> place(B.n_tris);          // {place, first place of the triangle's leaf}
+    for (uint32_t i = 0; i <= B.pool_ptr && B.n_tris > 0; ++i)
+        if (i != 1 && i != 2)
+            for (uint32_t k = B.first[i]; k < B.first[i] + B.count[i]; ++k) place[B.idx[k]] = make_uint2(k, B.first[i]);
+    arrange_long_leaves(B, order);
+    stage("long leaves arranged");
     std::vector<float4> triA(B.n_tris), triB(B.n_tris), attr(4 * (size_t)B.n_tris);
     std::vector<float2> triC(B.n_tris);
     std::vector<float4> triM(3 * (size_t)B.n_tris);
     parallel_for(B.n_tris, [&](size_t b, size_t e) {
         for (size_t k = b; k < e; ++k) {
-            const uint32_t id = B.idx[k];
+            const uint32_t id = order[k];
             const HostTri& t = B.tris[id];
             const f3 e1 = t.p1 - t.p0, e2 = t.p2 - t.p0;      // raytracer.cpp:289-290
             triA[k] = make_float4(e1.x, e1.y, e1.z, e2.x);
@@ -670,7 +726,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
                 const size_t gend = std::min(end, (k | 3) + 1);
                 f3 lo = {INFINITY, INFINITY, INFINITY}, hi = {-INFINITY, -INFINITY, -INFINITY};
                 for (size_t j = k; j < gend; ++j) {
-                    const HostTri& t = B.tris[B.idx[j]];
+                    const HostTri& t = B.tris[order[j]];
                     for (const f3& p : {t.p0, t.p1, t.p2}) {
                         lo = {std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z)};
                         hi = {std::max(hi.x, p.x), std::max(hi.y, p.y), std::max(hi.z, p.z)};
@@ -695,7 +751,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
                 f3 lo = {INFINITY, INFINITY, INFINITY}, hi = {-INFINITY, -INFINITY, -INFINITY};
                 bool sliver = false;
                 for (size_t k = 4 * g; k < std::min<size_t>(4 * g + 4, B.n_tris); ++k) {
-                    const HostTri& t = B.tris[B.idx[k]];
+                    const HostTri& t = B.tris[order[k]];
                     sliver = sliver || triangle_is_sliver(t.p0, t.p1, t.p2);
                     for (const f3& p : {t.p0, t.p1, t.p2}) {
                         lo = {std::min(lo.x, p.x), std::min(lo.y, p.y), std::min(lo.z, p.z)};
@@ -728,6 +784,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     MRT_HIP(c, c->d_triB.upload(triB, c->stream));
     MRT_HIP(c, c->d_triC.upload(triC, c->stream));
     MRT_HIP(c, c->d_triM.upload(triM, c->stream));
+    MRT_HIP(c, c->d_place.upload(place, c->stream));
     if (c->has_groups) MRT_HIP(c, c->d_triG.upload(triG, c->stream));
     MRT_HIP(c, c->d_attr.upload(attr, c->stream));
     MRT_HIP(c, c->d_tex.upload(tex, c->stream));
@@ -742,7 +799,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     if (int rc = raster_upload(c->raster, meshes, n_meshes, c->stream, err)) return fail(c, rc, err);
     MRT_HIP(c, hipStreamSynchronize(c->stream));
     stage("rasterizer arrays");
-    MRT_HIP(c, refit_prepare(c->refit, c->bvh, c->stream));
+    MRT_HIP(c, refit_prepare(c->refit, c->bvh, order, c->stream));
     stage("tree shape for refits");
     refresh_scene_view(c);
     c->scene.n_textures = n_textures;

@@ -3,13 +3,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "bvh_builder.h"
 
 namespace mrt {
 
 // The shape of the tree a context holds, as the refit kernels need it (device memory, made at scene upload).
 struct RefitState {
-    uint32_t* d_idx = nullptr;        // leaf-order slot -> triangle id (BVH::m_TriangleIdx)
+    uint32_t* d_idx = nullptr;        // slot of the device arrays -> triangle id
     uint32_t* d_parent = nullptr;     // node slot -> parent slot, 0xffffffff for the root
     uint32_t* d_leaves = nullptr;     // slots of the leaves
     unsigned int* d_arrived = nullptr;  // per node slot: children that have reported their box
@@ -17,7 +19,7 @@ struct RefitState {
     uint32_t n_tris = 0, n_slots = 0, n_leaves = 0;
 };
 
-hipError_t refit_prepare(RefitState& R, const HostBVH& B, hipStream_t stream);
+hipError_t refit_prepare(RefitState& R, const HostBVH& B, const std::vector<uint32_t>& order, hipStream_t stream);
 hipError_t refit_run(RefitState& R, const float* pos, const float* uv, const float* N, const int32_t* tri, float4* nodes, float4* triA, float4* triB,
                      float2* triC, float4* triM, uint4* triG, float4* attr, hipStream_t stream, float* largest, bool* coords_ok);
 void refit_release(RefitState& R);

@@ -138,9 +138,9 @@ void refit_release(RefitState& R) {
         if (e_ != hipSuccess) return e_;                                    \
     } while (0)
 
-// At scene upload: what a later refit needs of the tree's shape -- leaf-order triangle ids, every node's parent, the
-// list of leaves.  (Slots 1 and 2 of the node pool are unused and belong to no tree.)
-hipError_t refit_prepare(RefitState& R, const HostBVH& B, hipStream_t stream) {
+// At scene upload: what a later refit needs of the tree's shape -- the triangle ids in the order of the device arrays
+// (`order`: the leaf order with long leaves rearranged inside), every node's parent, the list of leaves.  (Slots 1 and 2 of the node pool are unused and belong to no tree.)
+hipError_t refit_prepare(RefitState& R, const HostBVH& B, const std::vector<uint32_t>& order, hipStream_t stream) {
     refit_release(R);
     R.n_tris = B.n_tris;
     R.n_slots = B.n_tris ? B.pool_ptr + 1 : 0;
@@ -161,7 +161,7 @@ hipError_t refit_prepare(RefitState& R, const HostBVH& B, hipStream_t stream) {
     REFIT_HIP(hipMalloc((void**)&R.d_leaves, (size_t)R.n_leaves * 4));
     REFIT_HIP(hipMalloc((void**)&R.d_arrived, (size_t)R.n_slots * 4));
     REFIT_HIP(hipMalloc((void**)&R.d_result, 2 * sizeof(uint32_t)));
-    REFIT_HIP(hipMemcpyAsync(R.d_idx, B.idx.data(), (size_t)R.n_tris * 4, hipMemcpyHostToDevice, stream));
+    REFIT_HIP(hipMemcpyAsync(R.d_idx, order.data(), (size_t)R.n_tris * 4, hipMemcpyHostToDevice, stream));
     REFIT_HIP(hipMemcpyAsync(R.d_parent, parent.data(), (size_t)R.n_slots * 4, hipMemcpyHostToDevice, stream));
     REFIT_HIP(hipMemcpyAsync(R.d_leaves, leaves.data(), (size_t)R.n_leaves * 4, hipMemcpyHostToDevice, stream));
     return hipStreamSynchronize(stream);           // the staging vectors go out of scope

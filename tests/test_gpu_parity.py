@@ -181,6 +181,49 @@ def test_soup_scenes_both_modes(n, lights):
     rt.close()
 
 
+def test_equal_distances_keep_the_reference_order_of_a_leaf():
+    """Every triangle of the scene exists eight times over, the copies shuffled: whole leaves of triangles that a ray hits
+    at exactly the same distance.  The reference keeps the copy that comes first in its leaf (strict `T < t`,
+    raytracer.cpp:1336-1344); the device arrays hold long leaves in another order and decide by the triangles' places in
+    the reference's order (kernels.hip: Tie).  Hit ids must equal the oracle's in both shaders, also from poses whose
+    tiles are handed out in sixteenths to teams of lanes."""
+    rng = np.random.RandomState(5)
+    base = scene_io.soup_scene(60, seed=77)
+    m = base["meshes"][0]
+    tri = np.asarray(m["tri"], np.int32).reshape(-1, 3)
+    pos, uv, norm, N = (np.asarray(m[k], np.float32) for k in ("pos", "uv", "norm", "N"))
+    pos = (pos * np.float32([0.2, 1.0, 0.2]) + np.float32([0, 0, -8])).astype(np.float32)      # (a compact cloud in front of both cameras)
+    copies = 8
+    order = rng.permutation(len(tri) * copies)
+    src = order % len(tri)                                   # which original triangle each new triangle copies
+    new_pos = pos[tri[src]].reshape(-1, 3)                   # three vertices of its own per copy
+    new_uv = uv[tri[src]].reshape(-1, 2)
+    new_norm = norm[tri[src]].reshape(-1, 3)
+    new_tri = np.arange(3 * len(src), dtype=np.int32).reshape(-1, 3)
+    scene = {"textures": base["textures"],
+             "meshes": [{"pos": new_pos, "uv": new_uv, "norm": new_norm, "N": N[src], "tri": new_tri, "texture": 0,
+                         "bounds": np.concatenate([new_pos.min(0), new_pos.max(0)]).astype(np.float32), "refl": 0.2, "refr": 0.3, "rindex": 1.5}]}
+    ora = oracle_lib.Oracle()
+    ora.add_scene(scene)
+    info = ora.build_bvh()
+    mm, fc, idx = ora.bvh_arrays()
+    assert fc[:, 1].max() >= 16                              # equal centroids cannot be told apart: long leaves
+    W, H = 256, 128
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(scene)
+    seen_ties = 0
+    for cam in (pose_cam(POSES[0]), oracle_lib.lookat((1.5, 0.5, -2), (0, 0, -8))):
+        for mode in (MODE_PACKET, MODE_RECURSIVE):
+            for _ in range(3):                               # (the later frames of a view split their expensive tiles)
+                fb, ids = rt.render(cam, mode=mode)
+            want = ora.render(cam, W, H, mode=mode)
+            assert np.array_equal(ids, want["ids"]), "%d hit ids differ" % int((ids != want["ids"]).sum())
+            assert colour_mismatch_fraction(fb, want["fb"]) <= 0.001
+            seen_ties += int((ids >= 0).sum())               # (every hit of this scene is a tie of eight)
+    assert seen_ties > 2000
+    rt.close()
+
+
 @pytest.mark.parametrize("scale", [1e5, 3e-4, 1e9, 1e-9])
 def test_scaled_scenes_exact_division_paths(scale):
     """The same soup blown up or shrunk, camera and lights with it.  Scales 1e5 and 3e-4 keep every
