@@ -224,11 +224,18 @@ int mrt_raster_render(mrt_ctx* ctx, const float cam_to_world[16],
                       uint32_t* fb, int pitch_px, float* zbuf, int32_t* tri_ids);
 
 /* The same frame into DEVICE memory, on `stream`: fb_dev (rows of pitch_px pixels, covered pixels only are
- * written), zbuf_dev and tri_ids_dev (optional, width*height each; every pixel written).  Returns when the
- * frame is complete: the call reads back the length of the frame's triangle lists to make sure its buffer was
- * large enough (and renders once more if a frame needs a longer list than any before it). */
+ * written), zbuf_dev and tri_ids_dev (optional, width*height each; every pixel written).  The frame is queued and
+ * the call returns; nothing is read back.  Frames of one context are queued on one stream at a time.  The lists of
+ * triangles per screen tile live in a buffer sized at mrt_scene_upload (four entries per triangle and 65,536 more);
+ * a frame that needs more is drawn without the entries that did not fit, and mrt_raster_wait says so. */
 int mrt_raster_render_device(mrt_ctx* ctx, const float cam_to_world[16],
                              void* fb_dev, int pitch_px, void* zbuf_dev, void* tri_ids_dev, void* stream);
+
+/* Waits for the last frame queued by mrt_raster_render_device (the counterpart of mrt_render_wait for the
+ * rasterizer; no counterpart in the reference, whose Rasterizer::Render returns a finished frame).  MRT_OK: every
+ * frame queued since the last call is complete.  MRT_E_LIMIT: one of them needed longer tile lists than the buffer
+ * held and is incomplete; the buffer has grown to what that frame needed: queue the frame again. */
+int mrt_raster_wait(mrt_ctx* ctx);
 
 /* ---- operator-level seam ------------------------------------------------------------ */
 

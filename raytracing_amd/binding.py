@@ -21,7 +21,7 @@ MODE_BVH_DEPTH = 2
 SYMBOLS = ("mrt_create", "mrt_destroy", "mrt_last_error", "mrt_version", "mrt_scene_upload", "mrt_scene_upload_lbvh", "mrt_scene_refit",
            "mrt_set_lights", "mrt_set_objects",
            "mrt_bvh_build_host", "mrt_render", "mrt_host_alloc", "mrt_host_free", "mrt_render_submit", "mrt_render_wait", "mrt_render_device", "mrt_render_device_noalloc", "mrt_render_device_part", "mrt_part_rows",
-           "mrt_raster_render", "mrt_raster_render_device", "mrt_trace_packets",
+           "mrt_raster_render", "mrt_raster_render_device", "mrt_raster_wait", "mrt_trace_packets",
            "mrt_trace_rays", "mrt_get_ray_counts", "mrt_get_tile_schedule", "mrt_camera_look_at")
 
 
@@ -96,6 +96,8 @@ def lib():
         L.mrt_part_rows.argtypes = [i32, i32, i32, i32]
         L.mrt_raster_render.argtypes = [vp, vp, vp, i32, vp, vp]
         L.mrt_raster_render_device.argtypes = [vp, vp, vp, i32, vp, vp, vp]
+        if hasattr(L, "mrt_raster_wait"):
+            L.mrt_raster_wait.argtypes = [vp]
         L.mrt_trace_packets.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp]
         L.mrt_trace_rays.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
         L.mrt_get_ray_counts.argtypes = [vp, vp]
@@ -322,11 +324,17 @@ class Raytracer:
         return fb, z, ids
 
     def raster_device(self, cam, fb_ptr, pitch, z_ptr=None, ids_ptr=None, stream=None):
-        """Rasterizer::Render(camera) into device memory (raw pointers)."""
+        """Rasterizer::Render(camera) into device memory (raw pointers).  The frame is queued on `stream`; raster_wait()
+        waits for it and tells whether its tile lists fitted their buffer."""
         cam = np.ascontiguousarray(getattr(cam, "transform", cam), np.float32).reshape(16)
         self._check(self.L.mrt_raster_render_device(self.h, _p(cam), C.c_void_p(fb_ptr), pitch, C.c_void_p(z_ptr) if z_ptr else None,
                                                     C.c_void_p(ids_ptr) if ids_ptr else None, C.c_void_p(stream) if stream else None),
                     "mrt_raster_render_device")
+
+    def raster_wait(self):
+        """Waits for the last frame queued by raster_device; raises MrtError (MRT_E_LIMIT) when a frame since the last call
+        was incomplete (queue it again: the buffer has grown)."""
+        self._check(self.L.mrt_raster_wait(self.h), "mrt_raster_wait")
 
     def trace_packets(self, O, D, rD, t):
         """BVH::TraverseRayPacket on (n_packets, 64, 3) ray arrays; returns (t, tri, u, v)."""

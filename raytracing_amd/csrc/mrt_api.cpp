@@ -796,7 +796,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     MRT_HIP(c, c->d_eye_g.ensure(std::max<size_t>(2, 2 * n_groups)));
     MRT_HIP(c, c->d_triG_eye.ensure(std::max<size_t>(1, n_groups)));
     stage("upload ray-path arrays");
-    if (int rc = raster_upload(c->raster, meshes, n_meshes, c->stream, err)) return fail(c, rc, err);
+    if (int rc = raster_upload(c->raster, meshes, n_meshes, order.size() == (size_t)B.n_tris ? order.data() : nullptr, c->stream, err)) return fail(c, rc, err);
     MRT_HIP(c, hipStreamSynchronize(c->stream));
     stage("rasterizer arrays");
     MRT_HIP(c, refit_prepare(c->refit, c->bvh, order, c->stream));
@@ -1144,6 +1144,14 @@ int mrt_raster_render_device(mrt_ctx* c, const float cam[16], void* fb_dev, int 
     if (int rc = raster_render(c->raster, tx, c->width, c->height, cam, (uint32_t*)fb_dev, pitch_px, (float*)zbuf_dev, (int32_t*)tri_ids_dev, true,
                                (hipStream_t)stream, err))
         return fail(c, rc, err);
+    return MRT_OK;
+}
+
+int mrt_raster_wait(mrt_ctx* c) {
+    if (!c) return MRT_E_ARG;
+    MRT_HIP(c, hipSetDevice(c->device));
+    std::string err;
+    if (int rc = raster_wait(c->raster, err)) return fail(c, rc, err);
     return MRT_OK;
 }
 

@@ -138,7 +138,7 @@ def main():
         elif what < 0.44:
             d = torch.full((H, W), 0x123456, dtype=torch.int32, device="cuda")
             rt.raster_device(cam, d.data_ptr(), W, stream=torch.cuda.current_stream().cuda_stream)
-            torch.cuda.synchronize()
+            rt.raster_wait()
             want = ref.raster(cam, fb=np.full((H, W), 0x123456, np.uint32))[0]
             assert np.array_equal(d.cpu().numpy().view(np.uint32), want), "op %d: device rasterizer frame differs" % op
             checked += 1

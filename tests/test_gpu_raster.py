@@ -157,7 +157,7 @@ def test_raster_pair_buffer_grows_between_frames():
 def test_raster_into_device_memory_equals_host_frame(maze_scene):
     """mrt_raster_render_device: frame, 1/z and triangle ids written into device memory (frame with a pitch wider
     than the image, covered pixels only) equal what mrt_raster_render hands back on the host; also on a context
-    whose first rasterizer call this is (the triangle-list buffer is sized inside the call)."""
+    whose first rasterizer call this is."""
     import torch
     W, H = 800, 600
     cam = pose_cam(POSES[1])
@@ -171,10 +171,51 @@ def test_raster_into_device_memory_equals_host_frame(maze_scene):
         z = torch.full((H, W), 7.0, dtype=torch.float32, device="cuda:0")
         ids = torch.full((H, W), -9, dtype=torch.int32, device="cuda:0")
         rt.raster_device(cam, fb.data_ptr(), W + 32, z_ptr=z.data_ptr(), ids_ptr=ids.data_ptr(), stream=stream)
-        torch.cuda.synchronize()
+        rt.raster_wait()
         want_fb, want_z, want_ids = rt.raster(cam, fb=np.full((H, W), 0x00123456, np.uint32))
         got = fb.cpu().numpy().view(np.uint32)
         assert np.array_equal(got[:, :W], want_fb) and (got[:, W:] == 0x00123456).all()
         assert np.array_equal(ids.cpu().numpy(), want_ids)
         assert np.array_equal(z.cpu().numpy().view(np.uint32), want_z.view(np.uint32))
         rt.close()
+
+
+def test_raster_device_frame_short_of_list_room_is_reported(maze_scene):
+    """Forty triangles that each fill a 4K frame need 40 x 8,160 tile-list entries, more than the buffer sized at upload
+    holds (4 per triangle + 65,536).  The frame queued into device memory is drawn without waiting; mrt_raster_wait
+    reports it incomplete (MRT_E_LIMIT) and the buffer has grown: the frame queued again is complete and equals the
+    host path's, which grows the buffer inside the call."""
+    import torch
+    from raytracing_amd import MrtError
+    W, H = 3840, 2160
+    n = 40
+    pos = np.zeros((3 * n, 3), np.float32)
+    for k in range(n):
+        z = -2.0 - 0.1 * k
+        pos[3 * k:3 * k + 3] = [[-40, -30, z], [40, -30, z], [0, 50, z]]
+    uv = np.tile(np.float32([[0, 0], [1, 0], [0.5, 1]]), (n, 1))
+    N = np.tile(np.float32([[0, 0, 1]]), (n, 1))
+    scene = {"textures": maze_scene["textures"],
+             "meshes": [{"pos": pos, "uv": uv, "norm": np.tile(np.float32([[0, 0, 1]]), (3 * n, 1)), "N": N,
+                         "tri": np.arange(3 * n, dtype=np.int32).reshape(-1, 3), "texture": 0,
+                         "bounds": np.concatenate([pos.min(0), pos.max(0)]), "refl": 0.0, "refr": 0.0, "rindex": 1.0}]}
+    cam = pose_cam(POSES[0])
+    stream = torch.cuda.current_stream().cuda_stream
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(scene)
+    fb = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
+    ids = torch.full((H, W), -9, dtype=torch.int32, device="cuda:0")
+    rt.raster_device(cam, fb.data_ptr(), W, ids_ptr=ids.data_ptr(), stream=stream)
+    with pytest.raises(MrtError, match="incomplete"):
+        rt.raster_wait()
+    rt.raster_wait()                                        # reported once
+    fb.zero_()
+    rt.raster_device(cam, fb.data_ptr(), W, ids_ptr=ids.data_ptr(), stream=stream)
+    rt.raster_wait()
+    fresh = Raytracer(W, H, device=0)
+    fresh.build_bvh(scene)
+    want_fb, _, want_ids = fresh.raster(cam, fb=np.zeros((H, W), np.uint32))
+    assert np.array_equal(fb.cpu().numpy().view(np.uint32), want_fb) and np.array_equal(ids.cpu().numpy(), want_ids)
+    assert (want_ids == 0).mean() > 0.9                     # the nearest triangle, drawn first, covers the frame
+    fresh.close()
+    rt.close()
