@@ -77,8 +77,9 @@ class Workload:
     with a stand-in kernel: scripts/native/coresidency.hip); with two buffers every frame would wait
     for a transfer that could only begin when the frame before it had ended."""
 
-    def __init__(self, name, scene, width, height, mode, grid, cam, rank, world, torch, dist, split="frames", rt=None, device="cuda"):
-        from raytracing_amd.multigpu import PartGather
+    def __init__(self, name, scene, width, height, mode, grid, cam, rank, world, torch, dist, split="frames", rt=None, device="cuda",
+                 exchange="native"):
+        from raytracing_amd.multigpu import NativeExchange, PartGather
         self.name, self.W, self.H, self.mode, self.grid, self.cam = name, width, height, mode, grid, cam
         self.rank, self.world, self.torch, self.dist, self.split = rank, world, torch, dist, split
         self.gpu = device == "cuda"        # the CPU tests of the multi-rank logic pass a stand-in renderer and device="cpu"
@@ -92,6 +93,27 @@ class Workload:
         self.rt = rt
         self.events, self.pending, self.i = [], [], 0
         self.inflight = {}                 # split == "frames": step index -> transfers that read that step's buffer
+        # exchange = "native": the shares or frames travel by libmrt_gather.so over a communicator of its own, the transport
+        # of `mrt_game --ranks` (RCCL send/recv queued on a side stream behind the frame); "torch": torch.distributed's
+        # batch_isend_irecv.  The native form needs one rank per GPU over RCCL; under gloo (CPU tests, the one-GPU rehearsal)
+        # the torch form is what runs, whatever was asked for.
+        self.exchange, self.exchange_note, self.nx, self.done = "torch", None, None, {}
+        if world > 1 and exchange == "native":
+            if not self.gpu or dist.get_backend() != "nccl":
+                self.exchange_note = "native exchange needs one rank per GPU over RCCL; this run has the %s backend" % dist.get_backend()
+            else:
+                try:
+                    self.nx = NativeExchange(width, height, rank, world, dist, 1)
+                    self.xs = torch.cuda.Stream()
+                    self.exchange = "native"
+                except (RuntimeError, OSError) as e:
+                    self.exchange_note = "native exchange not available (%s)" % e
+            # (every rank must take the same path: a rank that failed takes the others with it to the torch form)
+            ok = torch.tensor([1 if self.exchange == "native" else 0], dtype=torch.int32, device=device)
+            if exchange == "native" and (self.gpu and dist.get_backend() == "nccl"):
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok[0]) == 0 and self.exchange == "native":
+                    self.exchange, self.exchange_note = "torch", "native exchange not available on another rank"
         if world == 1 or split == "frames":
             self.fb = [torch.zeros((height, width), dtype=torch.int32, device=device) for _ in range(4 if world > 1 else 1)]
             self.frames = torch.zeros((world, height, width), dtype=torch.int32, device=device) if (world > 1 and rank == 0) else None
@@ -107,6 +129,10 @@ class Workload:
                 w.wait()
 
     def _finish_pending(self):
+        if self.exchange == "native":
+            self.xs.synchronize()
+            self.done.clear()
+            return
         self._retire(self.i)
         for w in self.pending:
             w.wait()
@@ -135,7 +161,11 @@ class Workload:
         fb = self.fb[self.i % len(self.fb)]
         step_no = self.i
         self.i += 1
-        if self.world > 1 and self.split == "frames":
+        if self.exchange == "native":
+            last_use = self.done.pop(step_no - len(self.fb), None)       # the transfer that read (rank 0, rows: wrote) this buffer last
+            if last_use is not None:
+                stream.wait_event(last_use)
+        elif self.world > 1 and self.split == "frames":
             self._retire(step_no - len(self.fb))      # the transfer that read this buffer last
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -145,6 +175,17 @@ class Workload:
             e1.record(stream)
             self.events.append((e0, e1))
         if self.world == 1:
+            return
+        if self.exchange == "native":
+            rendered = torch.cuda.Event()
+            rendered.record(stream)
+            self.xs.wait_event(rendered)
+            if self.split == "frames":
+                self.nx.frames(fb.data_ptr(), self.W, self.frames.data_ptr() if self.rank == 0 else None, self.xs.cuda_stream)
+            else:
+                self.nx.rows(fb.data_ptr(), self.W, self.xs.cuda_stream)
+            self.done[step_no] = torch.cuda.Event()
+            self.done[step_no].record(self.xs)
             return
         if self.host_transport:
             stream.synchronize()
@@ -195,15 +236,16 @@ class Workload:
         counts = self.rt.ray_counts()
         rays = np.array([counts["primary"], counts["shadow"], counts["secondary"], counts["primary_hits"]], np.int64)
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in self.events])) if self.events else 0.0
+        kern_min = kern_ms
         if self.world > 1:
-            t = torch.tensor([dt, kern_ms], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt, kern_ms, -kern_ms], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt, kern_ms = float(t[0]), float(t[1])
+            dt, kern_ms, kern_min = float(t[0]), float(t[1]), -float(t[2])
             r = torch.from_numpy(rays).to(dev)
             dist.all_reduce(r)
             rays = r.cpu().numpy()
         total = int(rays[0] + rays[1] + rays[2])
-        return {"seconds": dt, "ms_per_step": dt / steps * 1e3, "kernel_ms": kern_ms, "rays_per_step": total,
+        return {"seconds": dt, "ms_per_step": dt / steps * 1e3, "kernel_ms": kern_ms, "kernel_ms_min": kern_min, "rays_per_step": total,
                 "primary": int(rays[0]), "shadow": int(rays[1]), "secondary": int(rays[2]),
                 "mrays_per_s": total * steps / dt / 1e6}
 
@@ -282,7 +324,7 @@ def oracle_work_and_baseline(scene, W, H, mode, cam, threads, budget_s, pinned=T
     return {"counters": c, "rays": rays, "flops": flops_of(c), "best_s": best, "frames": frames, "fb": r["fb"], "distinct_cores": distinct}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -290,7 +332,14 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the sub-benchmarks beside the headline")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    args = ap.parse_args()
+    ap.add_argument("--exchange", choices=("native", "torch"), default="native",
+                    help="N > 1: how frames and shares reach rank 0: libmrt_gather.so over its own RCCL communicator (what mrt_game --ranks "
+                         "runs), or torch.distributed point-to-point operations")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
 
     import torch
     import torch.distributed as dist
@@ -323,7 +372,7 @@ def main():
     metric = "Mrays/sec (primary+secondary) and ms/frame at 1080p/8K, 1/2/4/8 MI355X"
     c4_workload = ("default maze scene (2120 triangles, 1 light), ONE 7680x4320 frame per step at 16 samples per pixel (4x4 grid: 30720x17280 "
                    "traced), packet path + shadow rays, default camera; scene replicated, 8-row tile rows dealt round-robin to the ranks, "
-                   "shares gathered on rank 0 (RCCL send/recv)")
+                   "shares gathered on rank 0 (RCCL send/recv, queued by libmrt_gather.so; --exchange torch: by torch.distributed)")
 
     def c4_roofline(r4):
         g4 = golden["c4_maze_8k_16spp_packet"]["counters"]
@@ -384,8 +433,9 @@ def main():
             b8 = ora["fb"].view(np.uint8).reshape(-1, 4).astype(np.int16)
             out["parity"].update({"pixels_beyond_1_255": float((np.abs(a8 - b8).max(axis=1) > 1).mean()), "pixels_different": int((a8 != b8).any(axis=1).sum())})
     else:
-        head = Workload("c4", scene, 7680, 4320, MODE_PACKET, 4, cam, rank, world, torch, dist, split="rows")
+        head = Workload("c4", scene, 7680, 4320, MODE_PACKET, 4, cam, rank, world, torch, dist, split="rows", exchange=args.exchange)
         res = head.run(args.steps, args.warmup)
+        got = head.frame() if rank == 0 else None
         if rank == 0:
             out = {
                 "metric": metric,
@@ -396,9 +446,12 @@ def main():
                            "primary": res["primary"], "shadow": res["shadow"], "secondary": res["secondary"], "resolution": [7680, 4320], "spp": 16,
                            "single_gpu_point": "c4_8k_16spp.value of the N = 1 line (whose headline is the 1080p recursive frame)"},
                 "roofline": c4_roofline(res),
+                # the slowest and the fastest rank's share of the frame: their kernel times show how even the deal of tile rows is
+                "kernel_ms_per_rank": {"min": round(res["kernel_ms_min"], 4), "max": round(res["kernel_ms"], 4)},
+                "exchange": head.exchange if head.exchange_note is None else "%s (%s)" % (head.exchange, head.exchange_note),
+                "parity": {"frame_hash_equals_oracle": _fbsum(got) == golden["c4_maze_8k_16spp_packet"]["fbsum"]},
             }
         if rehearsal:
-            got = head.frame() if rank == 0 else None
             if rank == 0:
                 ok = _fbsum(got) == golden["c4_maze_8k_16spp_packet"]["fbsum"]
                 print("rehearsal: 8K frame assembled from %d interleaved shares %s" % (world, "equals the oracle's frame" if ok else "DIFFERS"), file=sys.stderr)
@@ -520,12 +573,14 @@ def main():
         del c4
     if not args.no_extra and world > 1:
         # N whole 1080p recursive frames per step, one per rank, gathered on rank 0 (what a frame loop does with frames too small to cut)
-        fr = Workload("c2", scene, W, H, MODE_RECURSIVE, 1, cam, rank, world, torch, dist, split="frames")
+        fr = Workload("c2", scene, W, H, MODE_RECURSIVE, 1, cam, rank, world, torch, dist, split="frames", exchange=args.exchange)
         rf = fr.run(args.steps, args.warmup)
         if rank == 0:
             out["c2_frames_per_rank"] = {"workload": "the N = 1 headline workload, one whole 1920x1080 recursive frame per rank and step, frames gathered on rank 0",
                                          "scaling": "weak", "value": round(rf["mrays_per_s"], 3), "unit": "Mrays/s", "ms_per_step": round(rf["ms_per_step"], 5),
-                                         "kernel_ms": round(rf["kernel_ms"], 5), "frames_per_step": world}
+                                         "kernel_ms": round(rf["kernel_ms"], 5), "frames_per_step": world,
+                                         "kernel_ms_per_rank": {"min": round(rf["kernel_ms_min"], 5), "max": round(rf["kernel_ms"], 5)},
+                                         "exchange": fr.exchange if fr.exchange_note is None else "%s (%s)" % (fr.exchange, fr.exchange_note)}
         if rehearsal and rank == 0:
             fr._finish_pending()
             torch.cuda.synchronize()

@@ -45,6 +45,22 @@ int mrt_gather_frame_row(int height, int n_ranks, int block_tile_rows, int rank,
  * Shares without rows are skipped on both sides. */
 int mrt_gather_exchange(mrt_gather* g, void* nccl_comm, void* buf_dev, int pitch_px, void* stream);
 
+/* Whole frames, one per rank, gathered on rank 0 (a frame loop whose frames are too small to cut: every GPU renders
+ * a frame of its own).  Every rank passes the frame it rendered (height rows of pitch_px pixels; on ranks other than 0
+ * pitch_px must equal width: the frame is one ncclSend); rank 0 also passes frames_dev, n_ranks x height x width
+ * pixels, whose slot 0 receives a copy of its own frame and slot r the frame of rank r (one group of ncclRecv).
+ * Queued on `stream` without synchronising. */
+int mrt_gather_frames(mrt_gather* g, void* nccl_comm, const void* frame_dev, int pitch_px, void* frames_dev, void* stream);
+
+/* The communicator, for hosts that do not link RCCL themselves (a Python host through ctypes) and so that every host
+ * creates it the same way: rank 0 makes an id (MRT_GATHER_ID_BYTES bytes, RCCL's ncclUniqueId) and hands it to the
+ * other ranks by whatever means the launcher offers (a file, a key-value store); every rank then calls
+ * mrt_gather_comm_create with the GPU it renders on current.  The calls block until all n_ranks ranks have joined. */
+#define MRT_GATHER_ID_BYTES 128
+int  mrt_gather_comm_id(void* id_out);
+int  mrt_gather_comm_create(const void* id_in, int rank, int n_ranks, void** comm_out);
+void mrt_gather_comm_destroy(void* comm);
+
 /* The two halves of rank 0's side on their own, for transports other than RCCL (a single process
  * rehearsing the ranks, tests): the device buffer that receives `peer`'s packed share, and the kernel that
  * copies its rows into the frame.  mrt_gather_stage_local is the transport of a one-process rehearsal: it copies a

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <string.h>
+
 #include <string>
 #include <vector>
 
@@ -158,6 +160,63 @@ int mrt_gather_exchange(mrt_gather* g, void* nccl_comm, void* buf_dev, int pitch
     for (int r = 1; r < g->n_ranks; ++r)
         if (int rs = mrt_gather_scatter(g, r, buf_dev, pitch_px, stream)) return rs;
     return MRT_OK;
+}
+
+int mrt_gather_frames(mrt_gather* g, void* nccl_comm, const void* frame_dev, int pitch_px, void* frames_dev, void* stream) {
+    if (!g) return MRT_E_ARG;
+    if (!frame_dev) return fail(g, MRT_E_ARG, "null frame");
+    hipStream_t s = (hipStream_t)stream;
+    auto check = [&](ncclResult_t r, const char* what) {
+        if (r == ncclSuccess) return MRT_OK;
+        return fail(g, MRT_E_HIP, std::string(what) + ": " + ncclGetErrorString(r));
+    };
+    const size_t frame_px = (size_t)g->width * g->height;
+    if (g->rank != 0) {
+        if (!nccl_comm) return fail(g, MRT_E_ARG, "null communicator");
+        if (pitch_px != g->width) return fail(g, MRT_E_ARG, "a frame is sent as one buffer: pitch must equal width");
+        return check(ncclSend(frame_dev, frame_px, ncclUint32, 0, (ncclComm_t)nccl_comm, s), "ncclSend");
+    }
+    if (!frames_dev) return fail(g, MRT_E_ARG, "rank 0 needs the array of frames");
+    if (pitch_px < g->width) return fail(g, MRT_E_ARG, "pitch smaller than width");
+    const hipError_t e = hipMemcpy2DAsync(frames_dev, (size_t)g->width * 4, frame_dev, (size_t)pitch_px * 4, (size_t)g->width * 4, (size_t)g->height,
+                                          hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return fail(g, MRT_E_HIP, std::string("own frame copy: ") + hipGetErrorString(e));
+    if (g->n_ranks == 1) return MRT_OK;
+    if (!nccl_comm) return fail(g, MRT_E_ARG, "null communicator");
+    if (int rc = check(ncclGroupStart(), "ncclGroupStart")) return rc;
+    int rc = MRT_OK;
+    for (int r = 1; r < g->n_ranks && rc == MRT_OK; ++r)
+        rc = check(ncclRecv(static_cast<uint32_t*>(frames_dev) + (size_t)r * frame_px, frame_px, ncclUint32, r, (ncclComm_t)nccl_comm, s), "ncclRecv");
+    const int rc_end = check(ncclGroupEnd(), "ncclGroupEnd");
+    return rc != MRT_OK ? rc : rc_end;
+}
+
+static_assert(sizeof(ncclUniqueId) == MRT_GATHER_ID_BYTES, "mrt_gather.h promises the size of RCCL's communicator id");
+
+int mrt_gather_comm_id(void* id_out) {
+    if (!id_out) return fail(nullptr, MRT_E_ARG, "id_out is null");
+    ncclUniqueId id;
+    const ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, MRT_E_HIP, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+    memcpy(id_out, &id, sizeof id);
+    return MRT_OK;
+}
+
+int mrt_gather_comm_create(const void* id_in, int rank, int n_ranks, void** comm_out) {
+    if (!id_in || !comm_out) return fail(nullptr, MRT_E_ARG, "null id or comm_out");
+    *comm_out = nullptr;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(nullptr, MRT_E_ARG, "need 0 <= rank < n_ranks");
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof id);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = ncclCommInitRank(&comm, n_ranks, id, rank);
+    if (r != ncclSuccess) return fail(nullptr, MRT_E_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    *comm_out = comm;
+    return MRT_OK;
+}
+
+void mrt_gather_comm_destroy(void* comm) {
+    if (comm) (void)ncclCommDestroy((ncclComm_t)comm);
 }
 
 }  // extern "C"

@@ -33,7 +33,6 @@
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
-#include <rccl/rccl.h>
 #include <thread>
 
 #include "../../include/mrt_gather.h"
@@ -45,15 +44,15 @@ namespace {
 struct MultiOpts { int ranks = 1, rank = 0, block = 1, grid = 1, rehearse = 0; std::string id_file; };
 
 #define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) throw std::runtime_error(std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
-#define NCCL_OK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) throw std::runtime_error(std::string(#call) + ": " + ncclGetErrorString(r_)); } while (0)
 #define MRT_CHECK(ctx, call) do { int rc_ = (call); if (rc_ != MRT_OK) throw std::runtime_error(std::string(#call) + ": " + mrt_last_error(ctx)); } while (0)
 #define GATHER_OK(g, call) do { int rc_ = (call); if (rc_ != MRT_OK) throw std::runtime_error(std::string(#call) + ": " + mrt_gather_last_error(g)); } while (0)
 
 // rank 0 writes the id under a temporary name and renames it, so a reader never sees half a file
-ncclUniqueId share_id(const MultiOpts& m) {
-    ncclUniqueId id;
+struct CommId { unsigned char bytes[MRT_GATHER_ID_BYTES]; };
+CommId share_id(const MultiOpts& m) {
+    CommId id;
     if (m.rank == 0) {
-        NCCL_OK(ncclGetUniqueId(&id));
+        if (mrt_gather_comm_id(id.bytes) != MRT_OK) throw std::runtime_error(std::string("mrt_gather_comm_id: ") + mrt_gather_last_error(nullptr));
         const std::string tmp = m.id_file + ".tmp";
         FILE* f = fopen(tmp.c_str(), "wb");
         if (!f || fwrite(&id, sizeof id, 1, f) != 1) throw std::runtime_error("cannot write " + tmp);
@@ -82,8 +81,11 @@ int run_split(const MultiOpts& m, mrt_host::Scene& scene, int W, int H, int fram
     const int n = rehearsal ? m.rehearse : m.ranks, me = rehearsal ? 0 : m.rank;
     const uint32_t flags = (mode == "recursive" ? MRT_MODE_RECURSIVE : MRT_MODE_PACKET) | MRT_SPP_GRID(m.grid);
     HIP_OK(hipSetDevice(device >= 0 ? device : (rehearsal ? 0 : m.rank)));
-    ncclComm_t comm = nullptr;
-    if (!rehearsal) NCCL_OK(ncclCommInitRank(&comm, n, share_id(m), me));
+    void* comm = nullptr;
+    if (!rehearsal) {
+        const CommId id = share_id(m);
+        if (mrt_gather_comm_create(id.bytes, me, n, &comm) != MRT_OK) throw std::runtime_error(std::string("mrt_gather_comm_create: ") + mrt_gather_last_error(nullptr));
+    }
     Surface screen(W, H);
     Raytracer raytracer;
     raytracer.Init(&screen, -1);
@@ -133,7 +135,7 @@ int run_split(const MultiOpts& m, mrt_host::Scene& scene, int W, int H, int fram
         }
         if (!out.empty() && screen.SavePPM(out)) printf("wrote %s\n", out.c_str());
     }
-    if (comm) NCCL_OK(ncclCommDestroy(comm));
+    mrt_gather_comm_destroy(comm);
     mrt_gather_destroy(g);
     (void)hipFree(fb);
     if (packed) (void)hipFree(packed);

@@ -20,7 +20,9 @@ import numpy as np
 
 GATHER_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmrt_gather.so")
 GATHER_SYMBOLS = ("mrt_gather_create", "mrt_gather_destroy", "mrt_gather_last_error", "mrt_gather_share_rows",
-                  "mrt_gather_frame_row", "mrt_gather_exchange", "mrt_gather_staging", "mrt_gather_stage_local", "mrt_gather_scatter")
+                  "mrt_gather_frame_row", "mrt_gather_exchange", "mrt_gather_frames", "mrt_gather_comm_id", "mrt_gather_comm_create",
+                  "mrt_gather_comm_destroy", "mrt_gather_staging", "mrt_gather_stage_local", "mrt_gather_scatter")
+GATHER_ID_BYTES = 128
 _glib = None
 
 
@@ -42,6 +44,11 @@ def gather_lib():
         L.mrt_gather_share_rows.argtypes = [vp, i32]
         L.mrt_gather_frame_row.argtypes = [i32, i32, i32, i32, i32]
         L.mrt_gather_exchange.argtypes = [vp, vp, vp, i32, vp]
+        L.mrt_gather_frames.argtypes = [vp, vp, vp, i32, vp, vp]
+        L.mrt_gather_comm_id.argtypes = [vp]
+        L.mrt_gather_comm_create.argtypes = [vp, i32, i32, C.POINTER(vp)]
+        L.mrt_gather_comm_destroy.argtypes = [vp]
+        L.mrt_gather_comm_destroy.restype = None
         L.mrt_gather_staging.argtypes = [vp, i32]
         L.mrt_gather_staging.restype = vp
         L.mrt_gather_scatter.argtypes = [vp, i32, vp, i32, vp]
@@ -99,6 +106,61 @@ class NativeGather:
 
     def __del__(self):
         self.close()
+
+
+class NativeExchange:
+    """The exchange step of libmrt_gather.so with a communicator of its own: what `mrt_game --ranks` runs, driven from
+    Python.  Rank 0 makes the communicator id (mrt_gather_comm_id) and the ranks pass it round through the
+    torch.distributed process group that launched them (one object broadcast); every rank then joins
+    (mrt_gather_comm_create, on its current GPU).  rows(): the interleaved shares of one frame (mrt_gather_exchange);
+    frames(): one whole frame per rank (mrt_gather_frames).  Both are queued on the given stream and return at once."""
+
+    def __init__(self, width, height, rank, world, dist, block=1):
+        self.L = gather_lib()
+        self.rank, self.world = rank, world
+        self.comm = C.c_void_p()
+        self.gather = None
+        ident = C.create_string_buffer(GATHER_ID_BYTES)
+        box = [None]
+        if rank == 0:
+            rc = self.L.mrt_gather_comm_id(ident)
+            box[0] = ident.raw if rc == 0 else "mrt_gather_comm_id failed (%d): %s" % (rc, self.L.mrt_gather_last_error(None).decode())
+        dist.broadcast_object_list(box, src=0)           # (also when rank 0 failed: the others must not wait for an id for ever)
+        if not isinstance(box[0], bytes) or len(box[0]) != GATHER_ID_BYTES:
+            raise RuntimeError(box[0] if isinstance(box[0], str) else "the communicator id did not arrive")
+        ident = C.create_string_buffer(box[0], GATHER_ID_BYTES)
+        rc = self.L.mrt_gather_comm_create(ident, rank, world, C.byref(self.comm))
+        if rc != 0:
+            raise RuntimeError("mrt_gather_comm_create failed (%d): %s" % (rc, self.L.mrt_gather_last_error(None).decode()))
+        self.gather = NativeGather(width, height, rank, world, block)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.L.mrt_gather_last_error(self.gather.h).decode()))
+
+    def rows(self, buf_ptr, pitch, stream):
+        """rank 0: buf is the whole frame with its own share in place; others: the packed share."""
+        self._check(self.L.mrt_gather_exchange(self.gather.h, self.comm, C.c_void_p(buf_ptr), pitch, C.c_void_p(stream) if stream else None),
+                    "mrt_gather_exchange")
+
+    def frames(self, frame_ptr, pitch, frames_ptr, stream):
+        """every rank: the frame it rendered; rank 0 also: the world x height x width array the frames arrive in."""
+        self._check(self.L.mrt_gather_frames(self.gather.h, self.comm, C.c_void_p(frame_ptr), pitch, C.c_void_p(frames_ptr) if frames_ptr else None,
+                                             C.c_void_p(stream) if stream else None), "mrt_gather_frames")
+
+    def close(self):
+        if self.gather is not None:
+            self.gather.close()
+            self.gather = None
+        if self.comm:
+            self.L.mrt_gather_comm_destroy(self.comm)
+            self.comm = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def band_rows(height, world, rank):

@@ -363,6 +363,40 @@ def test_native_gather_scatter_reassembles_the_frame(maze_scene, world, block, p
     rt.close()
 
 
+def test_native_exchange_with_its_own_communicator_one_rank(maze_scene):
+    """multigpu.NativeExchange, the transport bench.py --gpus N drives: communicator id, communicator (RCCL, one rank:
+    all a one-GPU box can hold), whole-frame gather from a pitched frame and the share exchange of a frame of one share,
+    both queued on a side stream.  The many-rank forms of the same calls are rehearsed without RCCL by the tests above."""
+    import torch
+    from raytracing_amd.multigpu import NativeExchange
+
+    class OneRank:
+        def broadcast_object_list(self, box, src=0):
+            pass
+
+    W, H = 256, 128
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(maze_scene)
+    cam = pose_cam(POSES[1])
+    want, _ = rt.render(cam, mode=MODE_PACKET)
+    nx = NativeExchange(W, H, 0, 1, OneRank())
+    side = torch.cuda.Stream()
+    fb = torch.zeros((H, W + 64), dtype=torch.int32, device="cuda:0")
+    frames = torch.full((1, H, W), -1, dtype=torch.int32, device="cuda:0")
+    main = torch.cuda.current_stream()
+    rt.render_device(cam, fb.data_ptr(), W + 64, mode=MODE_PACKET, stream=main.cuda_stream)
+    rendered = torch.cuda.Event()
+    rendered.record(main)
+    side.wait_event(rendered)
+    nx.frames(fb.data_ptr(), W + 64, frames.data_ptr(), side.cuda_stream)
+    nx.rows(fb.data_ptr(), W + 64, side.cuda_stream)
+    side.synchronize()
+    assert np.array_equal(frames[0].cpu().numpy().view(np.uint32), want)
+    assert np.array_equal(fb[:, :W].cpu().numpy().view(np.uint32), want)
+    nx.close()
+    rt.close()
+
+
 def test_8k_16spp_frame_rows_match_oracle(maze_scene, maze_oracle, full_size):
     """The multi-GPU configuration at its full size (7680x4320, 4x4 sample grid = 530,841,600 primary
     rays): the whole frame is rendered once and its hash compared with the hash the oracle produced for this

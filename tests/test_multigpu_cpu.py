@@ -180,8 +180,12 @@ def _bench_worker(rank, world, port, W, H, split, out_path):
     o.add_scene(scene_io.load_scene(os.path.join(HERE, "golden", "maze.mrts")))
     o.build_bvh()
     frame = o.render(oracle_lib.lookat((6, 3, 12), (0, 0, 0)), W, H, mode=0, want_ids=False)["fb"].view(np.int32)
-    wl = bench.Workload("t", None, W, H, 0, 1, None, rank, world, torch, dist, split=split, rt=_OracleRenderer(frame), device="cpu")
+    # (the native exchange is asked for, as bench.py does by default: under gloo the torch form must take over, on every rank)
+    wl = bench.Workload("t", None, W, H, 0, 1, None, rank, world, torch, dist, split=split, rt=_OracleRenderer(frame), device="cpu",
+                        exchange="native" if split == "rows" else "torch")
+    assert wl.exchange == "torch" and (wl.exchange_note is None) == (split != "rows")
     res = wl.run(3, 1)
+    assert res["kernel_ms_min"] <= res["kernel_ms"]
     assert wl.rt.calls == 4
     assert res["rays_per_step"] == 16 * world
     if rank == 0:
@@ -208,6 +212,15 @@ def test_bench_workload_multi_rank_logic(tmp_path, world, split, maze_oracle):
     ref = maze_oracle.render(oracle_lib.lookat((6, 3, 12), (0, 0, 0)), W, H, mode=0, want_ids=False)["fb"]
     for f in got:
         assert np.array_equal(f, ref)
+
+
+def test_bench_exchange_option():
+    """bench.py --exchange: the native transport is the default, the torch form can be asked for, anything else is refused."""
+    import bench
+    assert bench.parse_args([]).exchange == "native" and bench.parse_args(["--gpus", "8"]).gpus == 8
+    assert bench.parse_args(["--exchange", "torch"]).exchange == "torch"
+    with pytest.raises(SystemExit):
+        bench.parse_args(["--exchange", "mpi"])
 
 
 def test_native_gather_exports_and_row_map_match_the_python_split():
