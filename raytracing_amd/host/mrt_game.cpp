@@ -5,7 +5,7 @@
 //   mrt_game [--scene assets/maze.obj | scene.mrts] [--size W H] [--frames N]
 //            [--mode packet|recursive|depth|raster] [--spheres] [--pos x y z --lookat x y z]
 //            [--out frame.ppm|frame.png] [--out-sequence prefix] [--overlay] [--dump-scene out.mrts] [--device N]
-//            [--script "W*30 RIGHT*10 O*5 SPACE*1" --dt 0.016] [--no-render] [--pipeline]
+//            [--script "W*30 RIGHT*10 O*5 U*3 SPACE*1" --dt 0.016] [--no-render] [--pipeline]
 //            [--ranks N --rank R --nccl-id FILE [--block B] [--spp-grid G]]  |  [--rehearse-ranks N]
 //
 // --script replays Game::HandleInput (game.cpp:41-75) without a keyboard: each token holds one key for N
@@ -219,14 +219,16 @@ int main(int argc, char** argv) {
         if (have_pose) { camera.SetPosition(pos); camera.LookAt(target); position = pos; }
         std::vector<float> light = {0, 5, 0, 1, 1, 1, 1};       // raytracer.cpp:396-399
         bool is_raytracer = mode != "raster", depth_view = mode == "depth";
+        // the two spheres Raytracer::Init creates (raytracer.cpp:404-412): the keys U and I move the first one
+        // (game.cpp:71-72) whether or not it is traced (--spheres)
+        std::vector<mrt_object> objects = {mrt_object{MRT_OBJECT_SPHERE, {1, 0, 0}, 0.5f, {1, 0, 1, 0}, 0.5f, 0.0f, 1.0f},
+                                           mrt_object{MRT_OBJECT_SPHERE, {-1, 0, 0}, 0.5f, {1, 1, 1, 1}, 0.0f, 0.5f, 1.5f}};
         Raytracer raytracer;
         auto t0 = std::chrono::steady_clock::now();
         if (!no_render) {
             raytracer.Init(&screen, device);                    // game.cpp:17-18
             raytracer.BuildBVH(scene);                          // game.cpp:34
-            if (spheres)                                        // raytracer.cpp:404-412
-                raytracer.SetObjects({mrt_object{MRT_OBJECT_SPHERE, {1, 0, 0}, 0.5f, {1, 0, 1, 0}, 0.5f, 0.0f, 1.0f},
-                                      mrt_object{MRT_OBJECT_SPHERE, {-1, 0, 0}, 0.5f, {1, 1, 1, 1}, 0.0f, 0.5f, 1.5f}});
+            if (spheres) raytracer.SetObjects(objects);
             printf("BuildBVH + upload: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         }
         auto add = [](vec3 a, vec3 b) { return vec3{a.x + b.x, a.y + b.y, a.z + b.z}; };
@@ -275,6 +277,9 @@ int main(int argc, char** argv) {
                 if (k == "O") light[1] += dt;
                 if (k == "P") light[1] -= dt;
                 if (!no_render && (k == "O" || k == "P")) raytracer.SetLights(light);
+                if (k == "U") objects[0].pos[1] += dt;          // game.cpp:71
+                if (k == "I") objects[0].pos[1] -= dt;          // game.cpp:72
+                if (!no_render && spheres && (k == "U" || k == "I")) raytracer.SetObjects(objects);
             }
             if (no_render) continue;
             if (pipeline && is_raytracer) {
@@ -312,8 +317,10 @@ int main(int argc, char** argv) {
         if (!keys.empty()) {
             printf("camera:");
             for (int i = 0; i < 16; ++i) { uint32_t u; memcpy(&u, &camera.transform[i], 4); printf(" %08x", u); }
-            uint32_t lu; memcpy(&lu, &light[1], 4);
-            printf("\nlight.y: %08x  renderer: %s\n", lu, is_raytracer ? "raytracer" : "rasterizer");
+            uint32_t lu, ou;
+            memcpy(&lu, &light[1], 4);
+            memcpy(&ou, &objects[0].pos[1], 4);
+            printf("\nlight.y: %08x  object0.y: %08x  renderer: %s\n", lu, ou, is_raytracer ? "raytracer" : "rasterizer");
         }
         if (no_render) return 0;
         const int counted = frames > 1 ? frames - 1 : 1;

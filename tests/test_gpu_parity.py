@@ -781,6 +781,35 @@ def test_cpp_host_driver_renders_reference_frame(tmp_path, known, loop):
     assert np.array_equal((rgb[..., 0] << 16) | (rgb[..., 1] << 8) | rgb[..., 2], fb & 0xFFFFFF)
 
 
+def test_cpp_host_driver_moves_the_first_sphere(tmp_path):
+    """The keys U and I (game.cpp:71-72) replayed by the driver's --script with the two spheres of raytracer.cpp:404-412
+    traced (--spheres): the last frame equals the frame of a context whose first sphere was moved by the same float32 steps."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "raytracing_amd", "host", "mrt_game")
+    out = str(tmp_path / "frame.ppm")
+    dt = np.float32(0.05)
+    subprocess.check_call([exe, "--scene", os.path.join(ROOT, "tests", "golden", "maze.mrts"), "--size", "512", "264", "--mode", "recursive",
+                           "--spheres", "--script", "U*6 I*1", "--dt", repr(float(dt)), "--pos", "0", "0.3", "2.5", "--lookat", "0", "0", "0", "--out", out])
+    with open(out, "rb") as f:
+        assert f.readline() == b"P6\n" and f.readline() == b"512 264\n" and f.readline() == b"255\n"
+        rgb = np.frombuffer(f.read(), np.uint8).reshape(264, 512, 3).astype(np.uint32)
+    y = np.float32(0)
+    for step in (1, 1, 1, 1, 1, 1, -1):
+        y = np.float32(y + dt) if step > 0 else np.float32(y - dt)
+    rt = Raytracer(512, 264, device=0)
+    rt.build_bvh(scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "maze.mrts")))
+    frames = []
+    for sy in (y, np.float32(0)):
+        rt.set_objects(np.float32([[0, 1, sy, 0, 0.5, 1, 0, 1, 0, 0.5, 0.0, 1.0], [0, -1, 0, 0, 0.5, 1, 1, 1, 1, 0.0, 0.5, 1.5]]))
+        frames.append(rt.render(oracle_lib.lookat((0, 0.3, 2.5), (0, 0, 0)), mode=MODE_RECURSIVE)[0])
+    rt.close()
+    got = (rgb[..., 0] << 16) | (rgb[..., 1] << 8) | rgb[..., 2]
+    assert np.array_equal(got, frames[0] & 0xFFFFFF)
+    assert not np.array_equal(frames[0], frames[1])          # (the sphere is in view: moving it changes the frame)
+
+
 @pytest.mark.parametrize("args", [["--rehearse-ranks", "3", "--size", "512", "264", "--mode", "recursive", "--block", "2"],
                                   ["--rehearse-ranks", "8", "--size", "960", "544", "--mode", "packet", "--spp-grid", "4"]],
                          ids=["3 ranks recursive", "8 ranks 16 spp"])

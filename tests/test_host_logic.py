@@ -232,19 +232,20 @@ def test_bvh_builder_under_sanitizers(tmp_path):
 @pytest.mark.skipif(not os.path.exists(DRIVER), reason="driver not built")
 def test_driver_input_script_follows_handle_input():
     """The headless driver's --script replay of Game::HandleInput (game.cpp:41-75): camera matrix and light
-    position after a key sequence equal a float32 restatement that uses the oracle's glm-exact LookAt."""
+    position (and the first sphere's, keys U and I) after a key sequence equal a float32 restatement that uses the oracle's glm-exact LookAt."""
     import subprocess
-    script = "W*7 RIGHT*5 D*3 UP*4 R*2 LEFT*9 S*4 DOWN*3 F*1 A*6 O*11 P*4 SPACE*3"
+    script = "W*7 RIGHT*5 D*3 UP*4 R*2 LEFT*9 S*4 DOWN*3 F*1 A*6 O*11 P*4 U*9 I*2 SPACE*3"
     dt = np.float32(0.0125)
     r = subprocess.run([DRIVER, "--scene", os.path.join(ROOT, "tests", "golden", "maze.mrts"), "--no-render", "--script", script,
                         "--dt", repr(float(dt)), "--pos", "1", "2", "3", "--lookat", "0", "0.5", "-4"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     got_cam = [int(x, 16) for x in r.stdout.split("camera:")[1].split("\n")[0].split()]
     got_light = int(r.stdout.split("light.y:")[1].split()[0], 16)
+    got_object = int(r.stdout.split("object0.y:")[1].split()[0], 16)
     f32 = np.float32
     M = oracle_lib.lookat((1, 2, 3), (0, 0.5, -4)).astype(np.float32).copy()
     pos = np.array([1, 2, 3], np.float32)
-    light, ray = f32(5), True
+    light, sphere, ray = f32(5), f32(0), True       # (the first sphere of raytracer.cpp:404-407 stands at y = 0)
     right, up, fwd, position = (lambda: M[0:3].copy()), (lambda: M[4:7].copy()), (lambda: -M[8:11]), (lambda: M[12:15].copy())
     for tok in script.split():
         k, n = tok.split("*")
@@ -266,6 +267,11 @@ def test_driver_input_script_follows_handle_input():
                 light = f32(light + dt)
             if k == "P":
                 light = f32(light - dt)
+            if k == "U":                          # game.cpp:71-72
+                sphere = f32(sphere + dt)
+            if k == "I":
+                sphere = f32(sphere - dt)
+    assert got_object == int(np.array([sphere], np.float32).view(np.uint32)[0])
     assert got_cam == [int(x) for x in M.view(np.uint32)]
     assert got_light == int(np.array([light], np.float32).view(np.uint32)[0])
     assert ("renderer: rasterizer" in r.stdout) == (not ray)
