@@ -700,8 +700,9 @@ def main():
                                                "kernel": "raster_setup + binning + raster_tile (whole frame)", "kernel_ms": round(kern5, 4), **traffic_of("c5", "frame_bytes_all_kernels"),
                                                "algorithmic_bytes_per_launch": int(bytes5),
                                                "bytes_model": "36 B x input triangles (%d) + 128 B x set-up records of drawn triangles (%d) + 8 B x pixels" % (n_in, g5["triangles_drawn"]),
-                                               "note": "the frame is not bound by memory: the tile kernel, 0.2 of the 0.36 ms, keeps the vector units busy about 70 % of its time "
-                                                       "(profiles/ pmc summary), and the binning passes wait for atomic adds served on the memory side",
+                                               "note": "the frame is not bound by memory traffic: the tile kernel (0.2 of the 0.36 ms) spends its time on the instructions "
+                                                       "of the triangles it draws and on waiting for list entries and records (counters under profiles/), and the binning "
+                                                       "passes wait for atomic adds that are served on the memory side",
                                                "reference_algorithm_model": {"bytes": int(bytes5_ref), "achieved_GBps": round(bytes5_ref / (kern5 * 1e-3) / 1e9, 2),
                                                                              "bytes_model": "8 B x fragments the reference's span fill visits (%d) + 36 B x triangles it draws (%d): "
                                                                                             "what the reference's own loop would move, overdraw included" % (g5["fragments"], g5["triangles_drawn"])},

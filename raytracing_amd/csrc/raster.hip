@@ -622,8 +622,9 @@ __device__ __forceinline__ unsigned int wave_max_u32(unsigned int v) {
 // same for all lanes: it is read by scalar loads.
 // (Tried and measured on the 1,000,000-triangle 4K frame, none faster: the record as one vector load with lane i taking
 // word i and the fields picked out by v_readlane, with two records on their way ahead; the same with two records per
-// load; the records of all of a batch's candidates requested at once and parked in LDS.  The kernel's vector unit is
-// busy about 70 % of the time, so it is the number of vector instructions per drawn triangle that counts.)
+// load; the records of all of a batch's candidates requested at once and parked in LDS; 8 or 16 waves per tile with
+// narrower strips (0.38 and 0.46 ms instead of 0.36).  What did shorten the frame was fewer vector instructions per
+// drawn triangle: the scalar loads, and one corner instead of four per block bound.)
 // (An earlier form kept the cells in LDS, gave each wave every fourth triangle of the list and tested depth with a
 // 64-bit LDS atomicMin: its waves spent more than half their time waiting for those atomics.)
 template <int NB>      // 8x8 blocks per wave: 4 (a 32x8 strip, 4 waves per tile), 2 (16x8, 8 waves) or 1 (8x8, 16 waves)
