@@ -12,9 +12,9 @@ namespace mrt {
 // The shape of the tree a context holds, as the refit kernels need it (device memory, made at scene upload).
 struct RefitState {
     uint32_t* d_idx = nullptr;        // slot of the device arrays -> triangle id
-    uint32_t* d_parent = nullptr;     // node slot -> parent slot, 0xffffffff for the root
+    uint32_t* d_inner = nullptr;      // slots of the inner nodes, sorted by height (1 = both children are leaves)
+    std::vector<uint32_t> level_start;  // host: d_inner[level_start[h] .. level_start[h + 1]) are the nodes of height h
     uint32_t* d_leaves = nullptr;     // slots of the leaves
-    unsigned int* d_arrived = nullptr;  // per node slot: children that have reported their box
     uint32_t* d_result = nullptr;     // [0] bits of the root box's largest coordinate, [1] a coordinate outside the division shortcut's range
     uint32_t n_tris = 0, n_slots = 0, n_leaves = 0;
 };

@@ -6,16 +6,21 @@
 //                    moved corners, with the subtractions of Triangle::Intersect (raytracer.cpp:289-290);
 //   refit_attributes one thread per triangle: face normal and the three uv pairs (raytracer.h:158-170 copies them out of
 //                    the mesh when the tree is built);
-//   refit_bounds     one thread per leaf: the leaf's box over its triangles' corners (compare + select from +-1e30 as
-//                    raytracer.h:258-262 does), then upwards -- at every inner node the second of the two children's
-//                    threads to arrive merges the two boxes and goes on, the first one ends (atomic arrival counters);
-//                    the thread that completes the root leaves the scene's largest coordinate behind, and every thread
-//                    reports a coordinate outside the range of the exact-division shortcut (mrt_math.h);
+//   refit_leaf_bounds, refit_inner_bounds
+//                    one thread per leaf: the leaf's box over its triangles' corners (compare + select from +-1e30 as
+//                    raytracer.h:258-262 does); then the inner nodes from the bottom up, one launch per height (a node's
+//                    height is one more than the taller of its children's, so a launch reads only boxes that earlier
+//                    launches wrote: no atomics and no fences inside a launch).  The thread that completes the root
+//                    leaves the scene's largest coordinate behind, and every thread reports a coordinate outside the
+//                    range of the exact-division shortcut (mrt_math.h).  (One launch in which the second of two children
+//                    to arrive at a node merged and went on, with arrival counters and a device-scope fence per step,
+//                    took 3.4 ms for a tree of 1,000,000 triangles: the fences, one behind the other up the tree.)
 //   refit_groups     one thread per group of four leaf-order slots: the padded binary16 box (device_scene.h: triG).
 // Vertex data is read from the rasterizer's device arrays (all meshes' vertices back to back, global vertex indices per
 // triangle), which mrt_scene_refit has refreshed before.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -60,12 +65,21 @@ __device__ __forceinline__ bool box_coords_ok(f3 lo, f3 hi) {
 }
 
 // result[0] = bits of the largest absolute coordinate of the root box, result[1] = 1 when some box has a coordinate the
-// exact-division shortcut does not cover (zero on entry).  arrived: one word per node slot, zero on entry.
-__global__ __launch_bounds__(256) void refit_bounds(uint32_t n_leaves, const uint32_t* leaves, const uint32_t* parent, const uint32_t* idx,
-                                                    const int32_t* tri, const float* pos, float4* nodes, unsigned int* arrived, uint32_t* result) {
+// exact-division shortcut does not cover (zero on entry).
+__device__ __forceinline__ void store_box(float4* nodes, uint32_t node, f3 lo, f3 hi, bool is_root, uint32_t* result) {
+    nodes[2 * (size_t)node] = make_float4(lo.x, lo.y, lo.z, nodes[2 * (size_t)node].w);
+    nodes[2 * (size_t)node + 1] = make_float4(hi.x, hi.y, hi.z, nodes[2 * (size_t)node + 1].w);
+    if (!box_coords_ok(lo, hi)) atomicOr(&result[1], 1u);
+    if (is_root) {
+        const float largest = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))), fmaxf(fabsf(lo.z), fabsf(hi.z)));
+        result[0] = __float_as_uint(largest);
+    }
+}
+__global__ __launch_bounds__(256) void refit_leaf_bounds(uint32_t n_leaves, const uint32_t* leaves, const uint32_t* idx, const int32_t* tri, const float* pos,
+                                                         float4* nodes, uint32_t* result) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_leaves) return;
-    uint32_t node = leaves[i];
+    const uint32_t node = leaves[i];
     const uint32_t first = __float_as_uint(nodes[2 * (size_t)node].w), count = __float_as_uint(nodes[2 * (size_t)node + 1].w);
     f3 lo = {1e30f, 1e30f, 1e30f}, hi = {-1e30f, -1e30f, -1e30f};
     for (uint32_t k = first; k < first + count; ++k) {
@@ -76,27 +90,18 @@ __global__ __launch_bounds__(256) void refit_bounds(uint32_t n_leaves, const uin
             hi = {gmax(hi.x, p.x), gmax(hi.y, p.y), gmax(hi.z, p.z)};
         }
     }
-    bool ok = true;
-    for (;;) {
-        nodes[2 * (size_t)node] = make_float4(lo.x, lo.y, lo.z, nodes[2 * (size_t)node].w);
-        nodes[2 * (size_t)node + 1] = make_float4(hi.x, hi.y, hi.z, nodes[2 * (size_t)node + 1].w);
-        ok = ok && box_coords_ok(lo, hi);
-        const uint32_t up = parent[node];
-        if (up == 0xffffffffu) {            // the root
-            const float largest = fmaxf(fmaxf(fmaxf(fabsf(lo.x), fabsf(hi.x)), fmaxf(fabsf(lo.y), fabsf(hi.y))), fmaxf(fabsf(lo.z), fabsf(hi.z)));
-            result[0] = __float_as_uint(largest);
-            break;
-        }
-        __threadfence();
-        if (atomicAdd(&arrived[up], 1u) == 0u) break;      // the other child's thread will come by and do the merge
-        __threadfence();
-        const uint32_t l = __float_as_uint(nodes[2 * (size_t)up].w), r = l + 1;
-        const float4 l0 = nodes[2 * (size_t)l], l1 = nodes[2 * (size_t)l + 1], r0 = nodes[2 * (size_t)r], r1 = nodes[2 * (size_t)r + 1];
-        lo = {gmin(l0.x, r0.x), gmin(l0.y, r0.y), gmin(l0.z, r0.z)};
-        hi = {gmax(l1.x, r1.x), gmax(l1.y, r1.y), gmax(l1.z, r1.z)};
-        node = up;
-    }
-    if (!ok) atomicOr(&result[1], 1u);
+    store_box(nodes, node, lo, hi, node == 0u, result);       // (a tree of one leaf: the leaf is the root)
+}
+// inner[0 .. n): the inner nodes of one height
+__global__ __launch_bounds__(256) void refit_inner_bounds(uint32_t n, const uint32_t* inner, float4* nodes, uint32_t* result) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t node = inner[i];
+    const uint32_t l = __float_as_uint(nodes[2 * (size_t)node].w), r = l + 1;
+    const float4 l0 = nodes[2 * (size_t)l], l1 = nodes[2 * (size_t)l + 1], r0 = nodes[2 * (size_t)r], r1 = nodes[2 * (size_t)r + 1];
+    const f3 lo = {gmin(l0.x, r0.x), gmin(l0.y, r0.y), gmin(l0.z, r0.z)};
+    const f3 hi = {gmax(l1.x, r1.x), gmax(l1.y, r1.y), gmax(l1.z, r1.z)};
+    store_box(nodes, node, lo, hi, node == 0u, result);
 }
 
 // groups: the scene has group boxes.  result[0] = largest coordinate of the new root box (refit_bounds): the padding is
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256) void refit_groups(uint32_t n_tris, const uint3
 }  // namespace
 
 void refit_release(RefitState& R) {
-    for (void* p : {(void*)R.d_idx, (void*)R.d_parent, (void*)R.d_leaves, (void*)R.d_arrived, (void*)R.d_result})
+    for (void* p : {(void*)R.d_idx, (void*)R.d_inner, (void*)R.d_leaves, (void*)R.d_result})
         if (p) (void)hipFree(p);
     R = RefitState();
 }
@@ -139,30 +144,44 @@ void refit_release(RefitState& R) {
     } while (0)
 
 // At scene upload: what a later refit needs of the tree's shape -- the triangle ids in the order of the device arrays
-// (`order`: the leaf order with long leaves rearranged inside), every node's parent, the list of leaves.  (Slots 1 and 2 of the node pool are unused and belong to no tree.)
+// (`order`: the leaf order with long leaves rearranged inside), the list of leaves, and the inner nodes sorted by height
+// (1 = both children are leaves ... the root's).  (Slots 1 and 2 of the node pool are unused and belong to no tree.)
 hipError_t refit_prepare(RefitState& R, const HostBVH& B, const std::vector<uint32_t>& order, hipStream_t stream) {
     refit_release(R);
     R.n_tris = B.n_tris;
     R.n_slots = B.n_tris ? B.pool_ptr + 1 : 0;
     if (R.n_tris == 0) return hipSuccess;
-    std::vector<uint32_t> parent(R.n_slots, 0xffffffffu), leaves, todo{0u};
+    // nodes in an order in which every node comes before its children (the root first); heights from its reverse
+    std::vector<uint32_t> leaves, top_down, todo{0u};
     leaves.reserve(R.n_slots / 2 + 1);
+    top_down.reserve(R.n_slots / 2 + 1);
     while (!todo.empty()) {
         const uint32_t n = todo.back();
         todo.pop_back();
         if (B.count[n] != 0) { leaves.push_back(n); continue; }
+        top_down.push_back(n);
         const uint32_t l = B.first[n];
-        parent[l] = n; parent[l + 1] = n;
         todo.push_back(l); todo.push_back(l + 1);
     }
+    std::vector<uint32_t> height(R.n_slots, 0u);
+    uint32_t tallest = 0;
+    for (size_t k = top_down.size(); k-- > 0;) {
+        const uint32_t n = top_down[k], l = B.first[n];
+        height[n] = 1u + std::max(height[l], height[l + 1]);
+        tallest = std::max(tallest, height[n]);
+    }
+    R.level_start.assign(tallest + 2, 0u);                  // level_start[h] .. level_start[h + 1]: the nodes of height h in `inner`
+    for (uint32_t n : top_down) ++R.level_start[height[n] + 1];
+    for (uint32_t h = 1; h < tallest + 2; ++h) R.level_start[h] += R.level_start[h - 1];
+    std::vector<uint32_t> inner(top_down.size()), at(R.level_start.begin(), R.level_start.end() - 1);
+    for (uint32_t n : top_down) inner[at[height[n]]++] = n;
     R.n_leaves = (uint32_t)leaves.size();
     REFIT_HIP(hipMalloc((void**)&R.d_idx, (size_t)R.n_tris * 4));
-    REFIT_HIP(hipMalloc((void**)&R.d_parent, (size_t)R.n_slots * 4));
+    REFIT_HIP(hipMalloc((void**)&R.d_inner, std::max<size_t>(1, inner.size()) * 4));
     REFIT_HIP(hipMalloc((void**)&R.d_leaves, (size_t)R.n_leaves * 4));
-    REFIT_HIP(hipMalloc((void**)&R.d_arrived, (size_t)R.n_slots * 4));
     REFIT_HIP(hipMalloc((void**)&R.d_result, 2 * sizeof(uint32_t)));
     REFIT_HIP(hipMemcpyAsync(R.d_idx, order.data(), (size_t)R.n_tris * 4, hipMemcpyHostToDevice, stream));
-    REFIT_HIP(hipMemcpyAsync(R.d_parent, parent.data(), (size_t)R.n_slots * 4, hipMemcpyHostToDevice, stream));
+    if (!inner.empty()) REFIT_HIP(hipMemcpyAsync(R.d_inner, inner.data(), inner.size() * 4, hipMemcpyHostToDevice, stream));
     REFIT_HIP(hipMemcpyAsync(R.d_leaves, leaves.data(), (size_t)R.n_leaves * 4, hipMemcpyHostToDevice, stream));
     return hipStreamSynchronize(stream);           // the staging vectors go out of scope
 }
@@ -175,12 +194,16 @@ hipError_t refit_run(RefitState& R, const float* pos, const float* uv, const flo
     *largest = 0.0f; *coords_ok = true;
     if (R.n_tris == 0) return hipSuccess;
     const dim3 block(256);
-    REFIT_HIP(hipMemsetAsync(R.d_arrived, 0, (size_t)R.n_slots * 4, stream));
     REFIT_HIP(hipMemsetAsync(R.d_result, 0, 2 * sizeof(uint32_t), stream));
     hipLaunchKernelGGL(refit_triangles, dim3((R.n_tris + 255u) / 256u), block, 0, stream, R.n_tris, (const uint32_t*)R.d_idx, tri, pos, triA, triB, triC, triM);
     hipLaunchKernelGGL(refit_attributes, dim3((R.n_tris + 255u) / 256u), block, 0, stream, R.n_tris, tri, uv, N, attr);
-    hipLaunchKernelGGL(refit_bounds, dim3((R.n_leaves + 255u) / 256u), block, 0, stream, R.n_leaves, (const uint32_t*)R.d_leaves, (const uint32_t*)R.d_parent,
-                       (const uint32_t*)R.d_idx, tri, pos, nodes, R.d_arrived, R.d_result);
+    hipLaunchKernelGGL(refit_leaf_bounds, dim3((R.n_leaves + 255u) / 256u), block, 0, stream, R.n_leaves, (const uint32_t*)R.d_leaves,
+                       (const uint32_t*)R.d_idx, tri, pos, nodes, R.d_result);
+    for (size_t h = 1; h + 1 < R.level_start.size(); ++h) {
+        const uint32_t n = R.level_start[h + 1] - R.level_start[h];
+        if (n == 0) continue;
+        hipLaunchKernelGGL(refit_inner_bounds, dim3((n + 255u) / 256u), block, 0, stream, n, (const uint32_t*)R.d_inner + R.level_start[h], nodes, R.d_result);
+    }
     if (triG)
         hipLaunchKernelGGL(refit_groups, dim3(((R.n_tris + 3u) / 4u + 255u) / 256u), block, 0, stream, R.n_tris, (const uint32_t*)R.d_idx, tri, pos,
                            (const uint32_t*)R.d_result, triG);
