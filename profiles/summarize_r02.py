@@ -51,7 +51,8 @@ def main():
                             "profiles/run_profile_r02.sh), raw counter values in KB converted to bytes per launch.  These are the L2's memory-side "
                             "requests, Infinity-Cache hits included.  FETCH_SIZE is NOT doubled: the x2 correction holds for 16-byte-per-lane streaming "
                             "reads, and the reads here are 16- and 32-byte node and triangle records fetched one per wave (scalar loads) or one per lane, "
-                            "shading attributes and texels."}
+                            "shading attributes and texels.  One kernel is such a stream: raster_setup reads its gathered triangle arrays 16 bytes per lane, so its "
+                            "share of c5.frame_bytes_all_kernels (54 MB of fetches in r03a) stands for about twice that."}
     for cfg, kern in DOMINANT.items():
         h = out.get(cfg, {}).get(kern)
         if not h:
@@ -69,8 +70,9 @@ def main():
             fk, wk = h["FETCH_SIZE"]["per_launch"], h["WRITE_SIZE"]["per_launch"]
             traffic[cfg] = {"kernel": kern, "bytes_per_launch": int((fk + wk) * 1024), "fetch_bytes": int(fk * 1024), "write_bytes": int(wk * 1024)}
             if cfg == "c5":      # the rasterizer frame is several kernels: all of them
-                tot_f = sum(v["FETCH_SIZE"]["per_launch"] for k, v in out[cfg].items() if "FETCH_SIZE" in v)
-                tot_w = sum(v["WRITE_SIZE"]["per_launch"] for k, v in out[cfg].items() if "WRITE_SIZE" in v)
+                # (raster_gather runs once per scene upload, not per frame)
+                tot_f = sum(v["FETCH_SIZE"]["per_launch"] for k, v in out[cfg].items() if "FETCH_SIZE" in v and "gather" not in k)
+                tot_w = sum(v["WRITE_SIZE"]["per_launch"] for k, v in out[cfg].items() if "WRITE_SIZE" in v and "gather" not in k)
                 traffic[cfg].update({"frame_bytes_all_kernels": int((tot_f + tot_w) * 1024)})
         derived[cfg] = dict(kernel=kern, **e)
     out["_derived"] = derived
