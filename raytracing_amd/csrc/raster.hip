@@ -674,9 +674,6 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
 #else
 #define RASTER_CLOCK(slot) ((void)0)
 #endif
-#if MRT_RASTER_EXP
-    unsigned int exp_acc = 0;
-#endif
     uint32_t t_cur = entry(begin), t_next = entry(begin + kBatch);
     Head h_cur = head(t_cur);
     RASTER_CLOCK(12);
@@ -727,10 +724,6 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
                                         ((unsigned int)__builtin_amdgcn_readlane((int)zk2, j) <= m2 ? 0x100u : 0u) |
                                         ((unsigned int)__builtin_amdgcn_readlane((int)zk3, j) <= m3 ? 0x1000u : 0u);
             if (blocks == 0) return;        // the bounds have dropped below the triangle since the batch was looked through
-#if MRT_RASTER_EXP == 4
-            exp_acc += (unsigned int)wi(kRecInfo);
-            return;
-#endif
             RASTER_COUNT(3, 1);
             RASTER_COUNT(4, __popc(blocks));
             const uint32_t bxw = (uint32_t)wi(kRecBox), byw = (uint32_t)wi(kRecBox + 1);
@@ -769,10 +762,6 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
             if constexpr (NB > 1) block(1, k1, m1);
             if constexpr (NB > 2) { block(2, k2, m2); block(3, k3, m3); }
         };
-#if MRT_RASTER_EXP == 3
-        exp_acc += (unsigned int)__popcll(todo);
-        todo = 0;
-#endif
         while (todo) {
             const int j = __ffsll((long long)todo) - 1;
             todo &= todo - 1ull;
@@ -781,9 +770,6 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
         t_cur = t_next; t_next = t_after; h_cur = h_next;
         RASTER_CLOCK(10);
     }
-#if MRT_RASTER_EXP
-    if (exp_acc == 0x7fffffffu) fb[0] = exp_acc;
-#endif
     {
         unsigned long long keys[NB];
         int xs[NB];
@@ -799,12 +785,7 @@ __global__ __launch_bounds__(1024 / NB) void raster_tile(const RasterTri* __rest
             at[b] = (size_t)y * W + xs[b];
             at_fb[b] = (size_t)y * fb_pitch + xs[b];
         }
-#if MRT_RASTER_EXP == 1
-#pragma unroll
-        for (int b = 0; b < NB; ++b) if (inside[b]) fb[at_fb[b]] = (uint32_t)keys[b];
-#else
         resolve_pixels<NB>(setup, keys, tx, xs, y, inside, at, at_fb, fb, keep_uncovered != 0, zbuf, ids);
-#endif
     }
 #ifdef MRT_LOOP_COUNTS
     __builtin_amdgcn_s_waitcnt(0);
