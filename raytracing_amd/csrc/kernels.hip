@@ -645,7 +645,6 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
             if constexpr (TEAM) {
                 // one triangle of the chunk per member
                 static_assert(MRT_LEAF_CHUNK == 16, "a team is the 16 lanes of a DPP row");
-                const float t_before = t;
                 const uint32_t j = (uint32_t)lane & 15u;
                 const int tri_before = h.tri;
                 if (j < n_now) tri_test<false>(sc.tri_a(first + j), sc.tri_b(first + j), sc.tri_c(first + j), O, D, t, h, wd, Tie{sc.place});
@@ -782,20 +781,10 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
                 slab_div_pair(l0, l1, r0, r1, R, shortcut, INFINITY, leftN, rightN, nl, nr);
             }
             const unsigned long long ml = __ballot(leftN) & m, mr = __ballot(rightN) & m;
-#ifdef MRT_SHADOW_NEAR_FIRST
-            // Any order gives the same answer; the child most of the rays enter first is the likelier one to block them
-            // soon, and a ray that is blocked leaves the traversal.
-            const unsigned long long both = ml & mr;
-            const bool right_first = both != 0 && 2 * __popcll(__ballot(nr < nl) & both) > __popcll(both);
-            if (right_first) {
-                if (ml) work.push(lane, wbits(l0), wbits(l1), ml);
-                if (mr) work.push(lane, wbits(r0), wbits(r1), mr);
-            } else
-#endif
-            {
-                if (mr) work.push(lane, wbits(r0), wbits(r1), mr);
-                if (ml) work.push(lane, wbits(l0), wbits(l1), ml);
-            }
+            // (Any order gives the same answer.  Entering first the child that most of the rays reach first, the likelier
+            // one to block them soon, was measured: 2.7 % slower.)
+            if (mr) work.push(lane, wbits(r0), wbits(r1), mr);
+            if (ml) work.push(lane, wbits(l0), wbits(l1), ml);
         }
     }
     return h.tri >= 0;
