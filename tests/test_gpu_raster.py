@@ -219,3 +219,38 @@ def test_raster_device_frame_short_of_list_room_is_reported(maze_scene):
     assert (want_ids == 0).mean() > 0.9                     # the nearest triangle, drawn first, covers the frame
     fresh.close()
     rt.close()
+
+
+def test_raster_device_frames_queued_back_to_back_many_meshes():
+    """A scene of more meshes than the set-up kernel carries in its arguments (16): the per-mesh texture table is then
+    copied to the device per frame from a host array the next call rewrites.  Three frames from different cameras (one
+    of which culls most meshes) queued into device memory without a wait in between equal the host path's frames."""
+    import torch
+    n_meshes, per = 24, 90
+    soup = scene_io.soup_scene(n_meshes * per, seed=5)
+    m = soup["meshes"][0]
+    parts = []
+    for j in range(n_meshes):
+        lo, hi = j * per, (j + 1) * per
+        v0, v1 = lo * 3, hi * 3
+        parts.append({"pos": m["pos"][v0:v1], "uv": m["uv"][v0:v1], "norm": m["norm"][v0:v1], "N": m["N"][lo:hi],
+                      "tri": (m["tri"][lo:hi] - v0).astype(np.int32), "texture": 0,
+                      "bounds": np.concatenate([m["pos"][v0:v1].min(0), m["pos"][v0:v1].max(0)]), "refl": 0.0, "refr": 0.0, "rindex": 1.0})
+    soup["meshes"] = parts
+    W, H = 640, 360
+    cams = [pose_cam(POSES[0]), oracle_lib.lookat((5, 1, 4), (0, 0, -20)), oracle_lib.lookat((0, 0.5, -23), (30, 0, -23))]
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(soup)
+    stream = torch.cuda.current_stream().cuda_stream
+    fbs = [torch.full((H, W), 0x00123456, dtype=torch.int32, device="cuda:0") for _ in cams]
+    ids = [torch.full((H, W), -9, dtype=torch.int32, device="cuda:0") for _ in cams]
+    for c, fb, i in zip(cams, fbs, ids):
+        rt.raster_device(c, fb.data_ptr(), W, ids_ptr=i.data_ptr(), stream=stream)
+    rt.raster_wait()
+    drawn = []
+    for c, fb, i in zip(cams, fbs, ids):
+        want_fb, _, want_ids = rt.raster(c, fb=np.full((H, W), 0x00123456, np.uint32))
+        assert np.array_equal(fb.cpu().numpy().view(np.uint32), want_fb) and np.array_equal(i.cpu().numpy(), want_ids)
+        drawn.append(int((want_ids >= 0).sum()))
+    assert min(drawn) > 0 and len(set(drawn)) == 3           # (three different frames, none empty)
+    rt.close()
