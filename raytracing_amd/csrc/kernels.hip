@@ -1520,7 +1520,31 @@ __device__ __forceinline__ uint32_t cost_key(uint32_t cost) {
 // (bits 0-7, in 1/256; 0 = not known) as measured in the first frame that split the tile, when the whole tile's cost
 // was known from the frame before; while the tile stays split, estimate = slowest sixteenth / ratio.  (One fixed ratio
 // for all tiles made the tiles it flattered fall under the splitting threshold and come back every other frame.)
-__global__ __launch_bounds__(1024) void tile_keys_kernel(uint32_t* cost, uint32_t* state, uint32_t* packed, uint32_t* hist, int n) {
+// While the camera moves, what was expensive in the previous frame is expensive a few tiles further on in this one.
+// tile_spread_kernel (two passes: along the rows, then along the columns) gives every tile the largest previous cost
+// within `radius` tiles of it, and tile_keys_kernel orders a tile by the larger of its own cost and `share` of that: a
+// cheap tile started early costs nothing, an expensive one started late costs the frame its tail.  Only the ORDER uses
+// it; a tile is split by its own cost.  FROM_COST: the input is the launch's raw cost words (a whole tile's clocks, or
+// with bit 31 the slowest sixteenth's: taken as it is, the smaller figure) -- else values of the first pass.
+template <bool FROM_COST>
+__global__ __launch_bounds__(256) void tile_spread_kernel(const uint32_t* in, uint32_t* out, int tiles_x, int n, int radius, int step) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const int x = i % tiles_x, row0 = i - x;
+    uint32_t best = 0u;
+    for (int d = -radius; d <= radius; ++d) {
+        int j;
+        if (step == 1) { const int xx = x + d; if (xx < 0 || xx >= tiles_x) continue; j = row0 + xx; }
+        else { j = i + d * tiles_x; if (j < 0) continue; }
+        if (j >= n) continue;
+        uint32_t v = in[j];
+        if (FROM_COST) v &= 0x7fffffffu;
+        best = v > best ? v : best;
+    }
+    out[i] = best;
+}
+__global__ __launch_bounds__(1024) void tile_keys_kernel(uint32_t* cost, uint32_t* state, uint32_t* packed, uint32_t* hist, int n,
+                                                         const uint32_t* nearby, float share) {
     __shared__ uint32_t count[256], base[256];
     const int t = threadIdx.x, i = (int)blockIdx.x * 1024 + t;
     if (t < 256) count[t] = 0;
@@ -1541,7 +1565,9 @@ __global__ __launch_bounds__(1024) void tile_keys_kernel(uint32_t* cost, uint32_
         }
         state[i] = ((whole >> 6) << 8) | ratio;
         cost[i] = 0u;            // the sixteenths of a tile leave their maximum (atomicMax)
-        key = cost_key(whole);
+        uint32_t rank_by = whole;
+        if (nearby) { const uint32_t around = (uint32_t)(share * (float)nearby[i]); rank_by = around > whole ? around : whole; }
+        key = cost_key(rank_by);
     }
     const uint32_t local = i < n ? atomicAdd(&count[key], 1u) : 0u;
     __syncthreads();
@@ -1623,10 +1649,19 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* packed
 }
 // n < 2^24.  cost, state, packed: n words each.  hist: 256 words, zero on entry.  order: `capacity` entries; n_entries receives how many were written (n, or
 // more when allow_split let some tiles be listed as sixteenths).
+// spread_a, spread_b: n words each, or null; with them and radius > 0 the order takes the costs of the tiles within
+// `radius` of a tile into account (tile_spread_kernel; tiles_x: tiles per row).
 hipError_t launch_order_tiles(uint32_t* cost, uint32_t* state, uint32_t* packed, uint32_t* hist, uint32_t* order, int n, bool allow_split, int n_waves,
-                              float budget_frac, int split_keys, size_t capacity, unsigned long long* n_entries, hipStream_t stream) {
+                              float budget_frac, int split_keys, size_t capacity, unsigned long long* n_entries,
+                              uint32_t* spread_a, uint32_t* spread_b, int tiles_x, int radius, float share, hipStream_t stream) {
     const dim3 grid((unsigned)((n + 1023) / 1024)), block(1024);
-    hipLaunchKernelGGL(tile_keys_kernel, grid, block, 0, stream, cost, state, packed, hist, n);
+    const bool spread = spread_a && spread_b && radius > 0 && tiles_x > 0;
+    if (spread) {
+        const dim3 g256((unsigned)((n + 255) / 256)), b256(256);
+        hipLaunchKernelGGL((tile_spread_kernel<true>), g256, b256, 0, stream, (const uint32_t*)cost, spread_a, tiles_x, n, radius, 1);
+        hipLaunchKernelGGL((tile_spread_kernel<false>), g256, b256, 0, stream, (const uint32_t*)spread_a, spread_b, tiles_x, n, radius, 0);
+    }
+    hipLaunchKernelGGL(tile_keys_kernel, grid, block, 0, stream, cost, state, packed, hist, n, spread ? (const uint32_t*)spread_b : (const uint32_t*)nullptr, share);
     hipLaunchKernelGGL(tile_order_kernel, grid, block, 0, stream, (const uint32_t*)packed, (const uint32_t*)hist, order, n, allow_split ? 1 : 0, n_waves,
                        budget_frac, (uint32_t)split_keys, (uint32_t)std::min<size_t>(capacity, 0xffffffffu), n_entries);
     return hipGetLastError();

@@ -27,7 +27,8 @@ hipError_t launch_eye_groups(const SceneDev& S, const float eye[3], float group_
 hipError_t prepare_render_kernels();
 hipError_t launch_depth_view(const SceneDev& S, const FrameDev& F, hipStream_t stream);
 hipError_t launch_order_tiles(uint32_t* cost, uint32_t* state, uint32_t* packed, uint32_t* hist, uint32_t* order, int n, bool allow_split, int n_waves,
-                              float budget_frac, int split_keys, size_t capacity, unsigned long long* n_entries, hipStream_t stream);
+                              float budget_frac, int split_keys, size_t capacity, unsigned long long* n_entries,
+                              uint32_t* spread_a, uint32_t* spread_b, int tiles_x, int radius, float share, hipStream_t stream);
 int resident_waves(int n_tiles, int n_cus, int threads, bool ordered);
 size_t resident_lds_bytes(int n_node_slots, int n_tris, int stack_entries);
 hipError_t launch_trace_packets(const SceneDev& S, int n_packets, const float* O, const float* D, const float* rD,
@@ -156,6 +157,8 @@ struct mrt_ctx {
     // per-tile clocks of the last persistent-kernel launch and the tile order derived from them;
     // cost_shape identifies the launch they belong to (0: none)
     DevBuf<uint32_t> d_tile_cost, d_tile_packed, d_tile_order, d_tile_state;
+    DevBuf<uint32_t> d_tile_spread_a, d_tile_spread_b;   // while the camera moves: the largest previous cost near every tile (kernels.hip: tile_spread_kernel)
+    float order_cam[16] = {};                            // the camera of the last frame whose tiles were ordered
     unsigned long long cost_shape = 0;
     // last_stream is only ever COMPARED with the stream of the next launch (it may be a caller's stream that no
     // longer exists); everything that has to wait for the last launch waits on last_done.
@@ -341,6 +344,8 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
             order_capacity = (size_t)F.n_tiles + kOrderExtra;
             MRT_HIP(c, c->d_tile_order.ensure(order_capacity));
             MRT_HIP(c, c->d_tile_state.ensure((size_t)F.n_tiles));
+            MRT_HIP(c, c->d_tile_spread_a.ensure((size_t)F.n_tiles));
+            MRT_HIP(c, c->d_tile_spread_b.ensure((size_t)F.n_tiles));
             cost = c->d_tile_cost.p; packed = c->d_tile_packed.p; order = c->d_tile_order.p; state = c->d_tile_state.p; last_shape = &c->cost_shape;
         }
         bool same_shape;
@@ -356,11 +361,17 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
             // traversal needs all 64 rays of a tile in one wave, and a sample grid is resolved across the tile's lanes
             const bool allow_split = mode == (int)MRT_MODE_RECURSIVE && g == 1;
             const int threads = env_int("MRT_RESIDENT_THREADS", kResidentThreads);
+            // A camera that has moved since the frame the costs come from: what was expensive there is expensive a few
+            // tiles further on here, so the order also looks at the costs within 4 % of the frame's width of a tile.
+            const bool moved = memcmp(c->order_cam, cam, 64) != 0;
+            const int radius = moved && !fixed ? std::max(1, F.tiles_x * env_int("MRT_SPREAD_PERMILLE", 40) / 1000) : 0;
             MRT_HIP(c, launch_order_tiles(cost, state, packed, reinterpret_cast<uint32_t*>(F.counters + kOrderHistBase), order, F.n_tiles, allow_split,
                                           resident_waves(F.n_tiles, c->n_cus, threads, true), (float)env_int("MRT_SPLIT_BUDGET", 50) * 0.01f, env_int("MRT_SPLIT_KEYS", 6), order_capacity,
-                                          F.counters + kOrderCountSlot, stream));
+                                          F.counters + kOrderCountSlot, fixed ? nullptr : c->d_tile_spread_a.p, fixed ? nullptr : c->d_tile_spread_b.p, F.tiles_x, radius,
+                                          (float)env_int("MRT_SPREAD_SHARE", 75) * 0.01f, stream));
             F.tile_order = order;
         }
+        memcpy(c->order_cam, cam, 64);
         F.tile_cost = cost;
     }
     if (mode == (int)MRT_MODE_PACKET && !resident) {
@@ -462,6 +473,7 @@ void mrt_destroy(mrt_ctx* c) {
     c->d_tex.release(); c->d_texels.release(); c->d_pal.release(); c->d_objects.release();
     c->d_fb.release(); c->d_ids.release(); c->d_counters.release();
     c->d_tile_cost.release(); c->d_tile_packed.release(); c->d_tile_order.release(); c->d_tile_state.release();
+    c->d_tile_spread_a.release(); c->d_tile_spread_b.release();
     raster_release(c->raster);
     refit_release(c->refit);
     if (c->h_stage) (void)hipHostFree(c->h_stage);

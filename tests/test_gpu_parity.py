@@ -672,6 +672,32 @@ def test_tile_order_from_previous_frame_changes_nothing(maze_scene, W, H):
     rt.close()
 
 
+@pytest.mark.parametrize("W,H", [(1920, 1080), (800, 600), (64, 40)])
+def test_tile_order_of_a_walking_camera_changes_nothing(maze_scene, W, H):
+    """While the camera moves from frame to frame the order of a frame's tiles also looks at the previous costs of the
+    tiles around each tile (kernels.hip: tile_spread_kernel), and small frames split tiles whose costs come from another
+    view.  Twelve frames of a camera walking sideways, then turning, equal the frames rendered with the ordering
+    switched off: pixels, hit IDs, ray counters."""
+    from raytracing_amd import Camera
+    rt = Raytracer(W, H, device=0)
+    rt.build_bvh(maze_scene)
+    plain = Raytracer(W, H, device=0)
+    plain.build_bvh(maze_scene)
+    cam = Camera()
+    for k in range(12):
+        if k < 8:
+            x, y, z = cam.get_position()
+            cam.set_position((x + 0.16, y, z))
+        else:
+            cam.look_at((np.float32(0.3 * (k - 7)), np.float32(0.1), np.float32(-1.0)))
+        fb, ids = rt.render(cam, mode=MODE_RECURSIVE)
+        want_fb, want_ids = plain.render(cam, mode=MODE_RECURSIVE, extra_flags=binding.FLAG_FRAME_ORDER)
+        assert np.array_equal(ids, want_ids) and np.array_equal(fb, want_fb), "frame %d" % k
+        assert rt.ray_counts() == plain.ray_counts()
+    rt.close()
+    plain.close()
+
+
 @pytest.mark.parametrize("W,H", [(512, 512), (800, 600), (256, 144)])
 def test_expensive_tiles_in_sixteenths_change_nothing(maze_scene, maze_oracle, W, H):
     """Small frames of the recursive shader: from the second frame of a view on, the most expensive tiles of the previous
