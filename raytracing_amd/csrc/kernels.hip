@@ -1523,8 +1523,8 @@ __device__ __forceinline__ uint32_t cost_key(uint32_t cost) {
 // While the camera moves, what was expensive in the previous frame is expensive a few tiles further on in this one.
 // tile_spread_kernel (two passes: along the rows, then along the columns) gives every tile the largest previous cost
 // within `radius` tiles of it, and tile_keys_kernel orders a tile by the larger of its own cost and `share` of that: a
-// cheap tile started early costs nothing, an expensive one started late costs the frame its tail.  Only the ORDER uses
-// it; a tile is split by its own cost.  FROM_COST: the input is the launch's raw cost words (a whole tile's clocks, or
+// cheap tile started early costs nothing, an expensive one started late costs the frame its tail.  The splitting of
+// expensive tiles goes by the same rank (tile_order_kernel).  FROM_COST: the input is the launch's raw cost words (a whole tile's clocks, or
 // with bit 31 the slowest sixteenth's: taken as it is, the smaller figure) -- else values of the first pass.
 template <bool FROM_COST>
 __global__ __launch_bounds__(256) void tile_spread_kernel(const uint32_t* in, uint32_t* out, int tiles_x, int n, int radius, int step) {
