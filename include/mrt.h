@@ -98,6 +98,19 @@ int mrt_scene_upload(mrt_ctx* ctx, const mrt_mesh* meshes, int n_meshes,
 int mrt_scene_upload_lbvh(mrt_ctx* ctx, const mrt_mesh* meshes, int n_meshes,
                           const mrt_texture* textures, int n_textures);
 
+/* Raytracer::BuildBVH(meshList) (game.cpp:34; raytracer.cpp:670-673) with two trees: everything mrt_scene_upload
+ * does -- the reference's own tree (raytracer.cpp:897-1203) serves every call as it does there --, and beside it the
+ * GPU-built tree of mrt_scene_upload_lbvh over the same triangles.  Frames of the recursive shader
+ * (MRT_MODE_RECURSIVE, a scene that fits the LDS, no analytic primitives) walk the second tree, which is the faster
+ * one, and report what BVH::Traverse (raytracer.cpp:1204-1264, 1328-1346) reports on the reference's tree: a ray's
+ * result is taken from the second tree only where it can be shown to be the reference's (no other triangle as near
+ * to within rounding, and the ray passes the hit triangle's leaf box of the reference's tree by the reference's
+ * arithmetic); the few tiles with a ray for which that cannot be shown are rendered again through the reference's tree
+ * within the same call.  Hit IDs, pixels and ray counts are those of mrt_scene_upload; only the time differs.  The
+ * upload costs both builds.  After mrt_scene_refit the second tree is no longer used. */
+int mrt_scene_upload_lbvh_exact(mrt_ctx* ctx, const mrt_mesh* meshes, int n_meshes,
+                                const mrt_texture* textures, int n_textures);
+
 /* Moving geometry without a new tree.  The reference can only build again (Raytracer::BuildBVH, raytracer.cpp:670-673,
  * the whole of BVH::BVH); this call keeps the tree the context holds -- the reference's or the GPU-built one -- takes the
  * meshes' new vertex positions, normals and uvs (same meshes in the same order with the same triangle counts and vertex
@@ -263,6 +276,12 @@ int mrt_get_ray_counts(mrt_ctx* ctx, uint64_t out[4]);
  * as sixteen 2x2-pixel parts each (15 more entries per such tile) so that a small frame does not wait for one wave.
  * Synchronises like mrt_get_ray_counts.  The pixels do not depend on any of this. */
 int mrt_get_tile_schedule(mrt_ctx* ctx, uint64_t out[2]);
+
+/* Scenes uploaded with mrt_scene_upload_lbvh_exact (no counterpart in the reference, which has one tree): out[0] = 1 if
+ * the most recent render walked the scene's second tree, else 0; out[1] = tiles of that render that were rendered again
+ * through the reference's tree because a ray's result could not be shown to be the reference's from the second tree
+ * alone.  Synchronises like mrt_get_ray_counts.  The pixels do not depend on any of this. */
+int mrt_get_second_tree_use(mrt_ctx* ctx, uint64_t out[2]);
 
 /* Camera::LookAt (scenedata.h:129-134): out = inverse(lookAt(pos, target, (0,1,0))) with the
  * vendored glm's operation order, so callers can form bit-identical camera matrices. */

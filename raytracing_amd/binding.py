@@ -18,7 +18,7 @@ MODE_PACKET = 0
 MODE_RECURSIVE = 1
 MODE_BVH_DEPTH = 2
 
-SYMBOLS = ("mrt_create", "mrt_destroy", "mrt_last_error", "mrt_version", "mrt_scene_upload", "mrt_scene_upload_lbvh", "mrt_scene_refit",
+SYMBOLS = ("mrt_create", "mrt_destroy", "mrt_last_error", "mrt_version", "mrt_scene_upload", "mrt_scene_upload_lbvh", "mrt_scene_upload_lbvh_exact", "mrt_get_second_tree_use", "mrt_scene_refit",
            "mrt_set_lights", "mrt_set_objects",
            "mrt_bvh_build_host", "mrt_render", "mrt_host_alloc", "mrt_host_free", "mrt_render_submit", "mrt_render_wait", "mrt_render_device", "mrt_render_device_noalloc", "mrt_render_device_part", "mrt_part_rows",
            "mrt_raster_render", "mrt_raster_render_device", "mrt_raster_wait", "mrt_trace_packets",
@@ -79,6 +79,7 @@ def lib():
         L.mrt_last_error.restype = C.c_char_p
         L.mrt_scene_upload.argtypes = [vp, C.POINTER(_Mesh), i32, C.POINTER(_Texture), i32]
         L.mrt_scene_upload_lbvh.argtypes = [vp, C.POINTER(_Mesh), i32, C.POINTER(_Texture), i32]
+        L.mrt_scene_upload_lbvh_exact.argtypes = [vp, C.POINTER(_Mesh), i32, C.POINTER(_Texture), i32]
         L.mrt_scene_refit.argtypes = [vp, C.POINTER(_Mesh), i32]
         L.mrt_set_lights.argtypes = [vp, vp, i32]
         L.mrt_set_objects.argtypes = [vp, C.POINTER(_Object), i32]
@@ -103,6 +104,8 @@ def lib():
         L.mrt_get_ray_counts.argtypes = [vp, vp]
         if hasattr(L, "mrt_get_tile_schedule"):         # (absent from older tuning builds named by MRT_LIB)
             L.mrt_get_tile_schedule.argtypes = [vp, vp]
+        if hasattr(L, "mrt_get_second_tree_use"):
+            L.mrt_get_second_tree_use.argtypes = [vp, vp]
         L.mrt_camera_look_at.argtypes = [vp, vp, vp]
         L.mrt_camera_look_at.restype = None
         _lib = L
@@ -224,11 +227,11 @@ class Raytracer:
 
     def build_bvh(self, scene, lbvh=False):
         """Raytracer::BuildBVH(meshList): flatten, build, upload.  lbvh=True: GPU-built linear BVH instead
-        of the reference's tree (fast, same distances, tie-breaks may differ)."""
+        of the reference's tree (fast, same distances, tie-breaks may differ).  lbvh="exact": that tree for the rays and
+        the reference's beside it for the tie-breaks of the single-ray traversal (mrt_scene_upload_lbvh_exact)."""
         meshes, textures, keep = _pack_scene(scene)
-        fn = self.L.mrt_scene_upload_lbvh if lbvh else self.L.mrt_scene_upload
-        self._check(fn(self.h, meshes, len(scene["meshes"]), textures, len(scene["textures"])),
-                    "mrt_scene_upload_lbvh" if lbvh else "mrt_scene_upload")
+        name = "mrt_scene_upload_lbvh_exact" if lbvh == "exact" else ("mrt_scene_upload_lbvh" if lbvh else "mrt_scene_upload")
+        self._check(getattr(self.L, name)(self.h, meshes, len(scene["meshes"]), textures, len(scene["textures"])), name)
         del keep
 
     def refit(self, scene):
@@ -312,6 +315,12 @@ class Raytracer:
         out = np.zeros(2, np.uint64)
         self._check(self.L.mrt_get_tile_schedule(self.h, _p(out)), "mrt_get_tile_schedule")
         return int(out[0]), int(out[1])
+
+    def second_tree_use(self):
+        """mrt_get_second_tree_use: (the last render walked the scene's second tree, tiles it rendered again through the first)."""
+        out = np.zeros(2, np.uint64)
+        self._check(self.L.mrt_get_second_tree_use(self.h, _p(out)), "mrt_get_second_tree_use")
+        return bool(out[0]), int(out[1])
 
     def raster(self, cam, fb=None, want_z=True, want_ids=True):
         """Rasterizer::Render(camera)."""

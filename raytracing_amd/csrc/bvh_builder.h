@@ -41,6 +41,6 @@ bool flatten_meshes(const mrt_mesh* meshes, int n_meshes, int n_textures, bool n
 void build_bvh(HostBVH& bvh);
 
 // lbvh.hip: a linear BVH built on the current GPU instead (not the reference's tree; see there).
-bool build_lbvh_device(HostBVH& bvh, hipStream_t stream, std::string& err);
+bool build_lbvh_device(HostBVH& bvh, hipStream_t stream, std::string& err, float inner_cost = 0.0f);
 
 }  // namespace mrt

@@ -64,6 +64,16 @@ struct SceneDev {
     int n_textures;
     int n_node_slots;     // node slots in use (poolPtr + 1)
     int coords_ok;        // every node bound is 0 or 2^-27 <= |c| <= 2^30: exact-division shortcut allowed
+    // Only when nodes / triA / triB / triC are the second, GPU-built tree of a scene uploaded with
+    // mrt_scene_upload_lbvh_exact (kernels.hip: hit_is_the_references): per triangle ID the box of its leaf in the
+    // REFERENCE's tree, {min.xyz, 0}, {max.xyz, 0}; and the reference's tree itself, for the rays that have to ask it.
+    const float4* leaf_box;
+    const float4* ref_nodes;
+    const float4* ref_triA;
+    const float4* ref_triB;
+    const float2* ref_triC;
+    const uint2* ref_place;
+    int ref_coords_ok;
 };
 
 struct FrameDev {
@@ -85,7 +95,8 @@ struct FrameDev {
     int n_queues;            // tile queues of the persistent kernel (set by its launcher: at most one per workgroup)
     uint32_t* fb;            // output frame (output resolution)
     int32_t* hit_ids;        // optional, traced-image resolution
-    // counters[0..15]: [5] watchdog code, [6] deepest pixel of the BVH-depth view, [7] entries of the tile order list.
+    // counters[0..15]: [5] watchdog code, [6] deepest pixel of the BVH-depth view, [7] entries of the tile order list,
+    // [8] rays traced again through the reference's tree (scenes with a second tree).
     // counters[kQueueBase + 16*q]: next index of tile queue q
     // (resident kernel), one cache line per queue.
     // Ray statistics live in kStatSlots groups of 16 words (128 bytes, one cache line each) after
@@ -109,6 +120,7 @@ struct FrameDev {
 };
 
 constexpr int kOrderCountSlot = 7;     // counters[7]: entries of the frame's tile order list (tile_order_kernel)
+constexpr int kRedoCountSlot = 8;      // counters[8]: rays of a frame through a scene's second tree that were traced again through the reference's
 constexpr int kOrderExtra = 16 * 2048; // entries the list may hold beyond one per tile (tiles handed out as sixteenths)
 constexpr int kStatSlots = 256;
 constexpr int kTileQueues = 32;

@@ -90,6 +90,12 @@ struct Watch {
         return true;
     }
 };
+// rays of a frame through a scene's second tree that were traced again through the reference's (hit_is_the_references);
+// must be called by all lanes the surrounding branch left active
+__device__ __forceinline__ void count_retraced(const Watch& wd, bool mine) {
+    const unsigned long long m = __ballot(mine);
+    if (wd.flag && m && (int)__lane_id() == __ffsll((long long)m) - 1) atomicAdd(wd.flag + (kRedoCountSlot - 5), (unsigned long long)__popcll(m));
+}
 
 // ---------------------------------------------------------------------------------------
 // Scene accessors: the traversals are written once and instantiated for both homes of the
@@ -106,6 +112,7 @@ struct SceneGlobalT {
     const v4u* triG;      // group boxes (device_scene.h)
     const v4f* triM;      // the same triangles as one 48-byte record each (device_scene.h): one address per test
     const uint2* place;   // triangle id -> {place in the tree's own leaf order, first place of its leaf} (device_scene.h)
+    const v4f* leaf_box = nullptr;      // (only the LDS-resident kernel walks a tree that needs them: SceneDev::leaf_box)
     static constexpr bool kMergedTris = true;
     __device__ __forceinline__ bool has_groups() const { return G; }
     __device__ __forceinline__ v4u group(uint32_t g) const { return triG[g]; }
@@ -145,6 +152,8 @@ struct SceneLds {
     MRT_LDS const v4f* nodes; MRT_LDS const v4f* triA; MRT_LDS const v4f* triB; MRT_LDS const v2f* triC;
     MRT_LDS const v4u* triG; bool groups;
     const uint2* place;   // (global memory: read only when two hits are equally far)
+    const v4f* leaf_box;  // (global memory: SceneDev::leaf_box, or null)
+    SceneGlobalT<false> ref;      // with leaf_box: the reference's own tree, in global memory (SceneDev::ref_nodes ...)
     static constexpr bool kMergedTris = false;
     __device__ __forceinline__ bool has_groups() const { return groups; }
     __device__ __forceinline__ v4u group(uint32_t g) const { return triG[g]; }
@@ -260,9 +269,46 @@ __device__ __forceinline__ bool slab_pair_shadow_interval(v4f l0, v4f l1, v4f r0
 // The device arrays hold the triangles of a long leaf in another order (device_scene.h), so the rule is applied by
 // name: place[id] = {the triangle's place in the reference's order, the first place of its leaf}.
 // place == nullptr: only "any hit" is asked.
+// unsure (scenes walked through another tree than the reference's, see hit_is_the_references): the lane's flag, set when
+// it has seen two candidates within 16 units in the last place of each other; null elsewhere.
 struct Tie {
     const uint2* place;
+    bool* unsure = nullptr;
 };
+
+// A scene may be walked through ANOTHER tree than the reference's (SceneDev::leaf_box; EXACT in the functions below):
+// boxes that stand back a little (so that no triangle is hidden from a ray that passes its test), visited in any
+// order, and dismissed by distance only when they begin clearly beyond the nearest hit so far (kExactCull).  Such a
+// walk tests every triangle that is as near as the nearest one, so it finds the smallest distance T of all triangles
+// whose test the ray passes, and the triangle W there.  The reference finds the same unless its own boxes, with their
+// rounding, keep it from W or the order of its visits matters.  Neither is the case when
+//   (a) no other triangle's hit lies within 16 units in the last place of T (tri_decide records such pairs), and
+//   (b) the ray passes the box of W's LEAF in the reference's tree by the reference's own arithmetic (tFar >= tNear and
+//       tFar > 0), entering it no later than 8 units in the last place after T, with no quotient 0/0:
+// the boxes of W's ancestors contain the leaf's, and the slab quotients are monotone in the box's bounds under correct
+// rounding, so by (b) every ancestor passes the two tests that do not involve the running distance; that distance is,
+// until W is tested, above T by more than 16 units (a), so `tNear < t` holds on the whole path (b), W is tested, is
+// strictly nearer than everything found before, and nothing found later is as near (a).  A ray that fails the check
+// sets its lane's `unsure` flag and is traced once more, through the reference's own tree in global memory
+// (shade_recursive), which by construction gives the reference's answer.
+// A shadow ray only asks whether the reference reaches SOME triangle the ray hits (occluded_wave), and its running
+// distance stays infinite until it does: the two tests of (b) decide that for every triangle by itself -- a leaf the
+// ray misses by the reference's arithmetic is never entered, one it passes is reached through ancestors that pass too
+// -- so a hit on a triangle of a leaf the ray misses is dropped and the walk goes on; only 0/0 leaves it undecided
+// (then the lane's shadow ray too goes through the reference's tree: direct_light).
+constexpr float kExactCull = 1.0f + 0x1p-10f;
+// undecided: a quotient of the leaf's box test is 0/0 (the ray runs inside a face of the box)
+__device__ __forceinline__ bool hit_is_the_references(const v4f* leaf_box, int tri, f3 O, f3 D, float T, bool nearest, bool& undecided) {
+    const v4f lo = leaf_box[2 * (size_t)tri], hi = leaf_box[2 * (size_t)tri + 1];
+    const bool nan_x = D.x == 0.0f && (lo.x == O.x || hi.x == O.x), nan_y = D.y == 0.0f && (lo.y == O.y || hi.y == O.y),
+               nan_z = D.z == 0.0f && (lo.z == O.z || hi.z == O.z);
+    undecided = nan_x || nan_y || nan_z;
+    float tNear, tFar;
+    slab_terms((xyz(lo) - O) / D, (xyz(hi) - O) / D, tNear, tFar);
+    bool ok = !undecided && (tFar >= tNear) && (tFar > 0);
+    if (nearest) ok = ok && (tNear <= T || (uint32_t)(__float_as_int(tNear) - __float_as_int(T)) <= 8u);
+    return ok;
+}
 __device__ __forceinline__ bool tie_goes_to(const Tie& tie, uint32_t id, int kept) {
     if (!tie.place || kept < 0) return false;
     const uint2 mine = tie.place[id], theirs = tie.place[kept];
@@ -295,6 +341,7 @@ __device__ __forceinline__ void tri_decide(float det, float un, float vn, float 
     live = live && !(v < 0 || u + v > 1);
     if (!__any(live)) return;
     const float T = tn * invDet;
+    if (tie.unsure) *tie.unsure = *tie.unsure || (live && !(T < 0.0f) && (uint32_t)(__float_as_int(T) - __float_as_int(t)) + 16u <= 32u);
     bool nearer = T < t;
     if (live && T == t) nearer = tie_goes_to(tie, id, h.tri);
     live = live && !(T < 0.0f) && nearer;
@@ -582,9 +629,12 @@ __device__ __forceinline__ void team_min_step(float& t, int& j) {
 // TEAM: the 16 lanes of every DPP row carry the SAME ray (render_tile); `lane` is then needed.  Such lanes take the
 // same way through the tree; in a leaf member j tests triangles j, j + 16, ... of it, and the members agree on the
 // nearest hit (the lowest triangle of equal distances) before any of them goes on.
-template <bool TEAM = false, class SC, typename STP>
+// EXACT: sc is not the reference's tree (hit_is_the_references); unsure: set when the lane's result is not certain.
+template <bool TEAM = false, bool EXACT = false, class SC, typename STP>
 __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool coords_ok, f3 O, f3 D, bool skip_ok, float& t, Hit& h, STP stack, Watch& wd,
-                                                 int lane = 0) {
+                                                 int lane = 0, bool* unsure = nullptr) {
+    static_assert(!(TEAM && EXACT), "tiles of such a scene are not handed out in sixteenths");
+    const Tie tie{sc.place, EXACT ? unsure : nullptr};
     h.tri = -1;
     if (n_tris == 0) return false;
     const v4f root0 = sc.node(0), root1 = sc.node(1);
@@ -610,7 +660,7 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
             const v4f l0 = pair[0], l1 = pair[1], r0 = pair[2], r1 = pair[3];
             bool leftN, rightN;
             float tNear, tNear2;
-            slab_div_pair(l0, l1, r0, r1, R, shortcut, t, leftN, rightN, tNear, tNear2);
+            slab_div_pair(l0, l1, r0, r1, R, shortcut, EXACT ? t * kExactCull : t, leftN, rightN, tNear, tNear2);
             // raytracer.cpp:1239-1262 as selects: go right when only the right child passes, or when
             // both pass and the right one is entered first (tNear2 < tNear); the other passing
             // child, if any, is deferred; with no passing child the next deferred node is taken.
@@ -671,7 +721,7 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
                 unsigned long long keep = 0;
                 for (uint32_t i = 0; i < n_groups; ++i) {
                     MRT_TICK(wd, 20);
-                    if (group_touched(sc.group(g0 + i), O, R.r, t)) keep |= 0xfull << (4u * i);
+                    if (group_touched(sc.group(g0 + i), O, R.r, EXACT ? t * kExactCull : t)) keep |= 0xfull << (4u * i);
                 }
                 if (long_leaf) todo &= (uint32_t)(keep >> shift);
             }
@@ -679,7 +729,7 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
                 MRT_TICK(wd, 1);
                 const uint32_t k = first + (uint32_t)__builtin_ctz(todo);
                 todo &= todo - 1u;
-                tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd, Tie{sc.place});
+                tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd, tie);
             }
             first += n_now; count -= n_now;
             if (count == 0) {
@@ -691,6 +741,10 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
                 }
             }
         }
+    }
+    if constexpr (EXACT) {
+        bool undecided;
+        if (h.tri >= 0 && !hit_is_the_references(sc.leaf_box, h.tri, O, D, t, true, undecided)) *unsure = true;
     }
     return h.tri >= 0;
 }
@@ -706,8 +760,11 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
 // Must be called by all 64 lanes; `take_part` selects the lanes that really have a ray.
 // ---------------------------------------------------------------------------------------
 // TEAM: the 16 lanes of every DPP row carry the same ray (render_tile) and share out the triangles of a leaf.
-template <bool TEAM = false, class SC>
-__device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coords_ok, f3 O, f3 D, bool take_part, bool skip_ok, int lane, Watch& wd) {
+// EXACT: as in traverse_nearest; a triangle in a leaf of the reference's tree that the ray misses blocks nothing.
+template <bool TEAM = false, bool EXACT = false, class SC>
+__device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coords_ok, f3 O, f3 D, bool take_part, bool skip_ok, int lane, Watch& wd,
+                                              bool* unsure = nullptr) {
+    static_assert(!(TEAM && EXACT), "tiles of such a scene are not handed out in sixteenths");
     if (n_tris == 0) return false;
     const v4f root0 = sc.node(0), root1 = sc.node(1);
     float tn;
@@ -720,6 +777,17 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
     float t = INFINITY;
     Hit h;
     h.tri = -1;
+    // EXACT: a hit just found counts only if the reference reaches that triangle (hit_is_the_references)
+    auto vet = [&]() {
+        if constexpr (EXACT) {
+            if (h.tri >= 0) {
+                bool undecided;
+                const bool counts = hit_is_the_references(sc.leaf_box, h.tri, O, D, t, false, undecided);
+                if (undecided) *unsure = true;
+                else if (!counts) { h.tri = -1; t = INFINITY; }
+            }
+        }
+    };
     LaneStack4 work;
     work.push(lane, wbits(root0), wbits(root1), m);
     unsigned long long found = 0;
@@ -744,7 +812,7 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
                 if (SC::kShadowGroups && sc.has_groups() && count >= (uint32_t)MRT_GROUP_MIN) {
                     walk_leaf_by_groups<false>(sc, first, count, O, R.r, r_ok, t, wd, [&](uint32_t k) {
                         MRT_TICK(wd, 5);
-                        if (h.tri < 0) tri_test_shared(sc, k, O, D, t, h, wd, Tie{nullptr});
+                        if (h.tri < 0) { tri_test_shared(sc, k, O, D, t, h, wd, Tie{nullptr}); vet(); }
                         return !__any(h.tri < 0);
                     });
                 } else if constexpr (SC::kPrefetchLeaf) {
@@ -756,14 +824,14 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
                         const uint32_t kn = k < last ? k + 1 : k;
                         const v4f An = sc.tri_a(kn), Bn = sc.tri_b(kn);
                         const v2f Cn = sc.tri_c(kn);
-                        if (h.tri < 0) tri_test<true>(A, B, C, O, D, t, h, wd, Tie{nullptr});
+                        if (h.tri < 0) { tri_test<true>(A, B, C, O, D, t, h, wd, Tie{nullptr}); vet(); }
                         if (!__any(h.tri < 0)) break;
                         A = An; B = Bn; C = Cn;
                     }
                 } else {
                     for (uint32_t k = first; k < first + count; ++k) {
                         MRT_TICK(wd, 5);
-                        if (h.tri < 0) tri_test_shared(sc, k, O, D, t, h, wd, Tie{nullptr});
+                        if (h.tri < 0) { tri_test_shared(sc, k, O, D, t, h, wd, Tie{nullptr}); vet(); }
                         if (!__any(h.tri < 0)) break;
                     }
                 }
@@ -910,9 +978,10 @@ __device__ __forceinline__ Surf object_surface(const SceneDev& S, int k, f3 hit)
 // ray per light, starting exactly on the surface (no epsilon).  Must be called by all 64 lanes.
 // REMAKE_COLOUR: the surface colour is made again from the packed palette entry after every shadow traversal
 // instead of being kept in four registers across it (the packet kernel is compiled for 64 registers).
-template <bool OBJ, bool REMAKE_COLOUR, bool TEAM = false, class SC>
+// EXACT (stack: the lane's traversal stack): see hit_is_the_references.
+template <bool OBJ, bool REMAKE_COLOUR, bool TEAM = false, bool EXACT = false, class SC, typename STP = int>
 __device__ __forceinline__ void direct_light(const SC& sc, const SceneDev& S, bool shade, const Surf& s, f3 hit, f4& finalColor,
-                                             int lane, uint32_t& n_shadow, Watch& wd) {
+                                             int lane, uint32_t& n_shadow, Watch& wd, STP stack = STP()) {
     const float lightStrength = shade ? 1.0f - (s.refr + s.refl) : 0.0f;
     const bool lit = shade && lightStrength > 0.0f;
     // the ambient term opens the sum; with REMAKE_COLOUR it is added when the first light's colour is at hand
@@ -924,7 +993,18 @@ __device__ __forceinline__ void direct_light(const SC& sc, const SceneDev& S, bo
     for (int i = 0; i < S.n_lights; ++i) {
         const float4 lp = S.lights[2 * i];
         const f3 L = lit ? normalize(xyz(lp) - hit) : f3{0.0f, 0.0f, 1.0f};
-        bool occluded = occluded_wave<TEAM>(sc, S.n_tris, S.coords_ok != 0, hit, L, lit, not_grazing(L, s.normal), lane, wd);
+        bool unsure = false;
+        bool occluded = occluded_wave<TEAM, EXACT>(sc, S.n_tris, S.coords_ok != 0, hit, L, lit, not_grazing(L, s.normal), lane, wd, &unsure);
+        if constexpr (EXACT) {
+            if (__any(unsure)) {          // Raytracer::IsOccluded itself (raytracer.cpp:414-418) on the reference's tree
+                count_retraced(wd, unsure);
+                if (unsure) {
+                    float tt = INFINITY;
+                    Hit hh;
+                    occluded = traverse_nearest<false, false>(sc.ref, S.n_tris, S.ref_coords_ok != 0, hit, L, true, tt, hh, stack, wd);
+                }
+            }
+        }
         if constexpr (OBJ) { if (lit && !occluded) occluded = objects_occlude(S, hit, L); }
         const float4 lc = S.lights[2 * i + 1];         // read after the traversal: nothing to keep alive across it
         f4 colorP = s.colorP;
@@ -970,7 +1050,7 @@ struct ShadeState {
     int stage;      // 0: reflection not tried yet, 1: refraction not tried yet, 2: done
 };
 
-template <bool OBJ, bool TEAM, class SC, typename STP>
+template <bool OBJ, bool TEAM, bool EXACT, class SC, typename STP>
 __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f3 O, f3 D, STP stack, int lane, Hit& primary,
                                               uint32_t& n_shadow, uint32_t& n_secondary, Watch& wd) {
     float frames[kFrames][kFrameWords];
@@ -988,7 +1068,17 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
         float t = tmax;
         bool isHit = false;
         MRT_PHASE_BEGIN(wd);
-        if (tracing) isHit = traverse_nearest<TEAM>(sc, S.n_tris, S.coords_ok != 0, O, D, skip_ok, t, h, stack, wd, lane);
+        bool unsure = false;
+        if (tracing) isHit = traverse_nearest<TEAM, EXACT>(sc, S.n_tris, S.coords_ok != 0, O, D, skip_ok, t, h, stack, wd, lane, &unsure);
+        if constexpr (EXACT) {
+            if (__any(unsure)) {          // not certainly the reference's result: BVH::Traverse itself on the reference's tree
+                count_retraced(wd, unsure);
+                if (unsure) {
+                    t = tmax;
+                    isHit = traverse_nearest<false, false>(sc.ref, S.n_tris, S.ref_coords_ok != 0, O, D, true, t, h, stack, wd);
+                }
+            }
+        }
         if constexpr (OBJ) { if (tracing) { trace_objects(S, O, D, t, h); isHit = h.tri != -1; } }
         MRT_PHASE_END(wd, 16);
         if (tracing && first) { primary = h; first = false; }
@@ -1002,7 +1092,7 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
         }
         f4 finalColor = {0, 0, 0, 0};
         MRT_PHASE_BEGIN(wd);
-        direct_light<OBJ, false, TEAM>(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
+        direct_light<OBJ, false, TEAM, EXACT>(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd, stack);
         MRT_PHASE_END(wd, 17);
         if (!tracing) continue;
         tracing = false;
@@ -1090,8 +1180,10 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // at column 2 * ((sub - 1) % 4), row 2 * ((sub - 1) / 4) of the tile.  A pixel's ray tree depends on nothing but its
 // own ray (raytracer.cpp:575-664), so sixteen such calls write the tile's pixels.
 // ---------------------------------------------------------------------------------------
-template <int MODE, bool OBJ, bool TEAM = false, class SC, typename STP>
+// EXACT (recursive shader, whole tiles): sc is another tree than the reference's (hit_is_the_references).
+template <int MODE, bool OBJ, bool TEAM = false, bool EXACT = false, class SC, typename STP>
 __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, const FrameDev& F, int tile, int lane, STP stack, int sub = 0) {
+    static_assert(!EXACT || (MODE == 1 && !TEAM), "only whole tiles of the recursive shader");
     // A sixteenth of a tile is four pixels for 64 lanes: every pixel gets a TEAM of 16 lanes (one DPP row) that all
     // carry the pixel's ray.  They walk the tree side by side (same ray, same decisions) and share out the triangles of
     // a leaf among themselves (traverse_nearest), which is what shortens the walk of a single ray tree; member 0 of a
@@ -1145,7 +1237,7 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
         MRT_PHASE_END(wd, 17);
         color = shade ? clamp01(finalColor) : MRT_BACKGROUND;
     } else {
-        color = shade_recursive<OBJ, TEAM>(sc, S, O, D, stack, lane, h, n_shadow, n_secondary, wd);
+        color = shade_recursive<OBJ, TEAM, EXACT>(sc, S, O, D, stack, lane, h, n_shadow, n_secondary, wd);
         if (!writer) { n_shadow = 0; n_secondary = 0; }
     }
     const uint32_t px = vec_to_pixel(color);
@@ -1395,7 +1487,8 @@ hipError_t launch_depth_view(const SceneDev& S, const FrameDev& F, hipStream_t s
 // GPU form of the reference's tile queue (threads.cpp:158-169: workers decrement one counter).
 // LDS: nodes | triA | triB | triC | per-lane stacks (16 bit entries: a resident scene has
 // fewer than 65536 node slots).
-template <int MODE>
+// EXACT: S is the scene's second tree (SceneDev::leaf_box; render_tile)
+template <int MODE, bool EXACT = false>
 #ifndef MRT_RESIDENT_WAVES
 #define MRT_RESIDENT_WAVES 4
 #endif
@@ -1430,7 +1523,9 @@ __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_t
         }
     }
     __syncthreads();
-    const SceneLds sc{l_nodes, l_a, l_b, l_c, l_g, S.triG != nullptr, S.place};
+    const SceneLds sc{l_nodes, l_a, l_b, l_c, l_g, S.triG != nullptr, S.place, reinterpret_cast<const v4f*>(S.leaf_box),
+                      SceneGlobalT<false>{reinterpret_cast<const v4f*>(S.ref_nodes), reinterpret_cast<const v4f*>(S.ref_triA), reinterpret_cast<const v4f*>(S.ref_triB),
+                                          reinterpret_cast<const v2f*>(S.ref_triC), nullptr, nullptr, S.ref_place}};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #ifdef MRT_LOOP_COUNTS
     const unsigned long long t_ready = __builtin_readcyclecounter();
@@ -1461,7 +1556,8 @@ __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_t
         const uint32_t entry = F.tile_order ? F.tile_order[pos] : (uint32_t)pos;
         const int tile = (int)(entry & 0xffffffu), sub = (int)(entry >> 24);
         const unsigned long long t0 = __builtin_readcyclecounter();
-        if (MODE == 1 && sub != 0) render_tile<MODE, false, MODE == 1>(sc, S, F, tile, lane, stack, sub);
+        if constexpr (EXACT) render_tile<MODE, false, false, true>(sc, S, F, tile, lane, stack);
+        else if (MODE == 1 && sub != 0) render_tile<MODE, false, MODE == 1>(sc, S, F, tile, lane, stack, sub);
         else render_tile<MODE, false>(sc, S, F, tile, lane, stack);
         if (F.tile_cost && lane == 0) {
             const unsigned long long dt = __builtin_readcyclecounter() - t0;
@@ -1738,14 +1834,14 @@ int resident_waves(int n_tiles, int n_cus, int threads, bool ordered) {
     return resident_blocks(n_tiles, n_cus, threads, ordered) * (std::max(64, std::min(kResidentThreads, threads / 64 * 64)) / 64);
 }
 
-template <int MODE>
+template <int MODE, bool EXACT = false>
 static hipError_t launch_resident_mode(const SceneDev& S, const FrameDev& F, int n_cus, int threads, hipStream_t stream) {
     const size_t lds = resident_lds_bytes(S.n_node_slots, S.n_tris, F.stack_entries);
     const int blocks = resident_blocks(F.n_tiles, n_cus, threads, F.tile_order != nullptr);
     threads = std::max(64, std::min(kResidentThreads, threads / 64 * 64));
     FrameDev Fq = F;
     Fq.n_queues = std::min(kTileQueues, blocks);          // every queue needs a workgroup of its own: nobody else drains it
-    hipLaunchKernelGGL((render_tiles_resident<MODE>), dim3((unsigned)blocks), dim3((unsigned)threads), lds, stream, S, Fq);
+    hipLaunchKernelGGL((render_tiles_resident<MODE, EXACT>), dim3((unsigned)blocks), dim3((unsigned)threads), lds, stream, S, Fq);
     return hipGetLastError();
 }
 
@@ -1754,7 +1850,9 @@ static hipError_t launch_resident_mode(const SceneDev& S, const FrameDev& F, int
 hipError_t prepare_render_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_tiles_resident<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&render_tiles_resident<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&render_tiles_resident<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&render_tiles_resident<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
 }
 
 // resident: use the LDS-resident persistent kernel (the caller has checked that the scene fits)
@@ -1763,6 +1861,13 @@ hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool re
     if (F.n_tiles <= 0) return hipSuccess;
     if (resident) return mode == 0 ? launch_resident_mode<0>(S, F, n_cus, resident_threads, stream) : launch_resident_mode<1>(S, F, n_cus, resident_threads, stream);
     return mode == 0 ? launch_global_mode<0>(S, F, stream) : launch_global_mode<1>(S, F, stream);
+}
+
+// A frame of the recursive shader through a scene's second tree (S.leaf_box and S.ref_* set, S.nodes ... the second
+// tree's, resident; no analytic primitives).  F.stack_entries: enough for either tree.
+hipError_t launch_render_second_tree(const SceneDev& S, const FrameDev& F, int n_cus, int resident_threads, hipStream_t stream) {
+    if (F.n_tiles <= 0) return hipSuccess;
+    return launch_resident_mode<1, true>(S, F, n_cus, resident_threads, stream);
 }
 
 // group_pad: the padding of the scene's group boxes (mrt_scene_upload), also the distance from a triangle's plane

@@ -322,8 +322,9 @@ struct Dev {
     } while (0)
 
 // Fills bvh.idx / nmin / nmax / first / count / pool_ptr / max_depth from bvh.tris.  Returns false with
-// err set on a HIP failure.  bvh.tris must not be empty.
-bool build_lbvh_device(HostBVH& B, hipStream_t stream, std::string& err) {
+// err set on a HIP failure.  bvh.tris must not be empty.  inner_cost: the price of an inner node in triangle tests
+// (0: kInnerCost); the higher, the larger the leaves and the fewer the nodes.
+bool build_lbvh_device(HostBVH& B, hipStream_t stream, std::string& err, float inner_cost_arg) {
     const uint32_t n = (uint32_t)B.tris.size();
     B.n_tris = n;
     B.n_nodes_alloc = 2 * n + 1;
@@ -377,7 +378,7 @@ bool build_lbvh_device(HostBVH& B, hipStream_t stream, std::string& err) {
     LBVH_HIP(temp.alloc(temp_bytes));
     LBVH_HIP(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, k0.p, k1.p, v0.p, v1.p, (int)n, 0, 30, stream));
     const int leaf_max = kLeafMax;
-    const float inner_cost = kInnerCost;
+    const float inner_cost = inner_cost_arg > 0.0f ? inner_cost_arg : kInnerCost;
     uint32_t n_kept = 0;
     constexpr bool morton_tree = false;         // true: the tree by Morton bits (lbvh_tree) instead of by clustering, for comparison
     uint32_t* order = v1.p;             // triangle ids in the tree's leaf order

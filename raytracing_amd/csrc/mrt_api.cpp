@@ -22,6 +22,7 @@
 
 namespace mrt {
 hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool resident, int n_cus, int resident_threads, hipStream_t stream);
+hipError_t launch_render_second_tree(const SceneDev& S, const FrameDev& F, int n_cus, int resident_threads, hipStream_t stream);
 hipError_t launch_eye_relative(const SceneDev& S, const float eye[3], float group_pad, float4* eye_nodes, float4* eye_tri, float4* eye_g, hipStream_t stream);
 hipError_t launch_eye_groups(const SceneDev& S, const float eye[3], float group_pad, uint4* out, hipStream_t stream);
 hipError_t prepare_render_kernels();
@@ -129,6 +130,14 @@ struct mrt_ctx {
     DevBuf<float2> d_triC;
     DevBuf<uint4> d_triG;
     DevBuf<float4> d_triM;
+    // mrt_scene_upload_lbvh_exact: a second, GPU-built tree over the same triangles, which frames of the recursive shader
+    // walk instead when it fits the LDS (kernels.hip: hit_is_the_references); everything else belongs to the first
+    struct FastTree {
+        DevBuf<float4> nodes, triA, triB, leaf_box;
+        DevBuf<float2> triC;
+        int n_slots = 0, coords_ok = 0, stack_entries = 0;
+        bool ok = false;
+    } fast;
     DevBuf<uint2> d_place;      // per triangle id: its place in the tree's own leaf order and its leaf's first place (device_scene.h: place)
     bool has_groups = false;
     // nodes and triangles relative to the eye of the last packet-path frame (kernels.hip: SceneGlobalEyeT), sized at
@@ -168,6 +177,7 @@ struct mrt_ctx {
     int last_n_lights = 0;                         // lights of the last launch (the shadow-ray counter is relative to it)
     int last_n_tiles = 0;                          // tiles of the last launch, and whether its queues handed out an order list
     bool last_ordered = false;
+    bool last_two_trees = false;                   // the last launch walked the scene's second tree (mrt_scene_upload_lbvh_exact)
     unsigned long long* last_counters = nullptr;   // counter block the last launch used (the context's own or the GPU's scratch)
     unsigned char* scratch_dev = nullptr;          // this GPU's copy of the scratch array (mrt_render_device_noalloc)
     unsigned long long noalloc_serial = 0;         // this context's launches into it
@@ -319,9 +329,12 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
         c->last_n_lights = 0;
         c->last_n_tiles = F.n_tiles;
         c->last_ordered = false;
+        c->last_two_trees = false;
         return MRT_OK;
     }
-    bool resident = c->resident && mode == (int)MRT_MODE_RECURSIVE && c->scene.n_objects == 0;
+    // a scene with a second tree (mrt_scene_upload_lbvh_exact): the recursive shader walks that one, in the persistent kernel
+    const bool two_trees = c->fast.ok && mode == (int)MRT_MODE_RECURSIVE && c->scene.n_objects == 0 && env_int("MRT_TWO_TREES", 1) != 0;
+    bool resident = two_trees || (c->resident && mode == (int)MRT_MODE_RECURSIVE && c->scene.n_objects == 0);
     if (env_int("MRT_RESIDENT_PACKET", 0)) resident = c->resident && c->scene.n_objects == 0;
     if (resident && F.n_tiles < (1 << 24) && !(flags & MRT_FLAG_FRAME_ORDER)) {
         // Launches of the same shape follow each other in a frame loop with a slowly moving camera:
@@ -359,7 +372,7 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
         if (same_shape) {
             // expensive tiles of the recursive shader may be listed as sixteenths (kernels.hip: tile_order_kernel); the packet
             // traversal needs all 64 rays of a tile in one wave, and a sample grid is resolved across the tile's lanes
-            const bool allow_split = mode == (int)MRT_MODE_RECURSIVE && g == 1;
+            const bool allow_split = mode == (int)MRT_MODE_RECURSIVE && g == 1 && !two_trees;
             const int threads = env_int("MRT_RESIDENT_THREADS", kResidentThreads);
             // A camera that has moved since the frame the costs come from: what was expensive there is expensive a few
             // tiles further on here, so the order also looks at the costs within 4 % of the frame's width of a tile.
@@ -387,6 +400,17 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
         F.eye_nodes = c->d_eye_nodes.p; F.eye_tri = c->d_eye_tri.p; F.eye_g = c->d_eye_g.p;
     }
     SceneDev S = c->scene;
+    if (two_trees) {
+        SceneDev fast = c->scene;
+        fast.nodes = c->fast.nodes.p; fast.triA = c->fast.triA.p; fast.triB = c->fast.triB.p; fast.triC = c->fast.triC.p;
+        fast.triG = nullptr; fast.triM = nullptr; fast.place = nullptr; fast.leaf_box = c->fast.leaf_box.p;
+        fast.n_node_slots = c->fast.n_slots; fast.coords_ok = c->fast.coords_ok;
+        fast.ref_nodes = S.nodes; fast.ref_triA = S.triA; fast.ref_triB = S.triB; fast.ref_triC = S.triC; fast.ref_place = S.place;
+        fast.ref_coords_ok = S.coords_ok;
+        FrameDev Ff = F;
+        Ff.stack_entries = c->fast.stack_entries;        // (enough for either tree: mrt_scene_upload_lbvh_exact)
+        MRT_HIP(c, launch_render_second_tree(fast, Ff, c->n_cus, env_int("MRT_RESIDENT_THREADS", kResidentThreads), stream));
+    } else {
     if (mode == (int)MRT_MODE_RECURSIVE && S.triG) {
         // the recursive shader's primary rays read the scene's own group boxes: this frame's copy of them stands
         // back where the eye grazes a triangle (rewritten when the eye or the scene has changed, like the arrays above)
@@ -400,6 +424,7 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
         S.triG = c->d_triG_eye.p;
     }
     MRT_HIP(c, launch_render(S, F, mode, resident, c->n_cus, env_int("MRT_RESIDENT_THREADS", kResidentThreads), stream));
+    }
     MRT_HIP(c, hipEventRecord(c->last_done, stream));
     c->last_stream = stream;
     c->launched = true;
@@ -407,6 +432,7 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
     c->last_n_lights = c->scene.n_lights;
     c->last_n_tiles = F.n_tiles;
     c->last_ordered = F.tile_order != nullptr;
+    c->last_two_trees = two_trees;
     return MRT_OK;
 }
 
@@ -474,6 +500,7 @@ void mrt_destroy(mrt_ctx* c) {
     c->d_fb.release(); c->d_ids.release(); c->d_counters.release();
     c->d_tile_cost.release(); c->d_tile_packed.release(); c->d_tile_order.release(); c->d_tile_state.release();
     c->d_tile_spread_a.release(); c->d_tile_spread_b.release();
+    c->fast.nodes.release(); c->fast.triA.release(); c->fast.triB.release(); c->fast.triC.release(); c->fast.leaf_box.release();
     raster_release(c->raster);
     refit_release(c->refit);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -506,7 +533,7 @@ int mrt_set_lights(mrt_ctx* c, const float* pos_rgba7, int n) {
     return MRT_OK;
 }
 
-enum class TreeSource { Reference, Lbvh };
+enum class TreeSource { Reference, Lbvh, LbvhExact };
 static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures, TreeSource source);
 
 int mrt_set_objects(mrt_ctx* c, const mrt_object* objects, int n) {
@@ -540,6 +567,10 @@ int mrt_scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt
 
 int mrt_scene_upload_lbvh(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures) {
     return scene_upload(c, meshes, n_meshes, textures, n_textures, TreeSource::Lbvh);
+}
+
+int mrt_scene_upload_lbvh_exact(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const mrt_texture* textures, int n_textures) {
+    return scene_upload(c, meshes, n_meshes, textures, n_textures, TreeSource::LbvhExact);
 }
 
 static int scene_refit(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes);
@@ -583,6 +614,7 @@ static int scene_refit(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes) {
         c->group_pad = largest * 0x1p-12f;
         c->scene.coords_ok = coords_ok ? 1 : 0;
     }
+    c->fast.ok = false;         // (the second tree of mrt_scene_upload_lbvh_exact is not refitted: frames go through the first from here on)
     c->has_scene = true;
     c->cost_shape = 0;          // tile costs of the old geometry say little about the new one
     ++c->scene_serial;          // (the eye-relative copies of the old arrays are stale)
@@ -821,6 +853,72 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     c->resident = B.n_tris > 0 && slots < 65536 &&
                   resident_lds_bytes((int)slots, (int)B.n_tris, c->stack_entries) + 256 <= (size_t)kLdsBudget;
     c->resident = c->resident && env_int("MRT_RESIDENT", 1) != 0;      // 0 forces the global-memory kernel
+    c->fast.ok = false;
+    if (source == TreeSource::LbvhExact && B.n_tris > 0) {
+        // the second tree: built on the GPU over the same triangles, kept only if the persistent kernel can hold it in LDS
+        // (with ever larger leaves until its nodes, the triangles and the waves' stacks fit)
+        HostBVH T;
+        T.tris = B.tris;
+        size_t fslots = 0;
+        int fstack = 0;
+        bool fits = false;
+        const int first_cost = env_int("MRT_SECOND_TREE_COST", 0);
+        for (float inner_cost : {first_cost > 0 ? (float)first_cost * 0.1f : 1.5f, 2.5f, 4.0f, 6.0f, 10.0f}) {
+            if (!build_lbvh_device(T, c->stream, err, inner_cost)) return fail(c, MRT_E_HIP, err);
+            fslots = (size_t)T.pool_ptr + 1;
+            fstack = std::max(T.max_depth + 2, c->stack_entries);        // the waves' stacks serve walks of either tree
+            fits = fstack <= kStackDepth && fslots < 65536 && resident_lds_bytes((int)fslots, (int)T.n_tris, fstack) + 256 <= (size_t)kLdsBudget;
+            if (timing) fprintf(stderr, "mrt_scene_upload: second tree at inner cost %.1f: %zu node slots, %u triangles, stack %d, LDS %zu of %d bytes\n", inner_cost, fslots,
+                                T.n_tris, fstack, resident_lds_bytes((int)fslots, (int)T.n_tris, fstack) + 256, kLdsBudget);
+            if (fits) break;
+        }
+        stage("second tree (GPU)");
+        if (fits && env_int("MRT_RESIDENT", 1) != 0) {
+            // The reference's boxes decide what the reference finds, rounding included; this tree's must only never hide a
+            // triangle from a ray that passes its test.  A ray through a triangle's edge that lies in a face of its box can
+            // miss the box by the rounding of the slab quotients (2^-22 of the distances involved), so every box but the
+            // root's (the gate every ray passes first: the same box, the same arithmetic in both trees) stands back by
+            // 2^-16 of the scene's largest coordinate.
+            const float pad = largest * 0x1p-16f;
+            std::vector<float4> fnodes(2 * fslots), fA(T.n_tris), fB(T.n_tris), fbox(2 * (size_t)T.n_tris);
+            std::vector<float2> fC(T.n_tris);
+            bool fcoords = true;
+            for (size_t i = 0; i < fslots; ++i) {
+                const float p = i == 0 ? 0.0f : pad;
+                const f3 lo = {T.nmin[i].x - p, T.nmin[i].y - p, T.nmin[i].z - p}, hi = {T.nmax[i].x + p, T.nmax[i].y + p, T.nmax[i].z + p};
+                fnodes[2 * i] = make_float4(lo.x, lo.y, lo.z, bits2f(T.first[i]));
+                fnodes[2 * i + 1] = make_float4(hi.x, hi.y, hi.z, bits2f(T.count[i]));
+                if (i == 1 || i == 2) continue;
+                for (float v : {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z}) fcoords = fcoords && div_shortcut_coord_ok(v);
+            }
+            for (size_t k = 0; k < T.n_tris; ++k) {
+                const uint32_t id = T.idx[k];
+                const HostTri& t = T.tris[id];
+                const f3 e1 = t.p1 - t.p0, e2 = t.p2 - t.p0;      // raytracer.cpp:289-290
+                fA[k] = make_float4(e1.x, e1.y, e1.z, e2.x);
+                fB[k] = make_float4(e2.y, e2.z, t.p0.x, t.p0.y);
+                fC[k] = make_float2(t.p0.z, bits2f(id));
+            }
+            for (uint32_t i = 0; i <= B.pool_ptr; ++i) {
+                if (i == 1 || i == 2) continue;
+                for (uint32_t k = B.first[i]; k < B.first[i] + B.count[i]; ++k) {       // (count 0: an inner node)
+                    fbox[2 * (size_t)B.idx[k]] = make_float4(B.nmin[i].x, B.nmin[i].y, B.nmin[i].z, 0.0f);
+                    fbox[2 * (size_t)B.idx[k] + 1] = make_float4(B.nmax[i].x, B.nmax[i].y, B.nmax[i].z, 0.0f);
+                }
+            }
+            MRT_HIP(c, c->fast.nodes.upload(fnodes, c->stream));
+            MRT_HIP(c, c->fast.triA.upload(fA, c->stream));
+            MRT_HIP(c, c->fast.triB.upload(fB, c->stream));
+            MRT_HIP(c, c->fast.triC.upload(fC, c->stream));
+            MRT_HIP(c, c->fast.leaf_box.upload(fbox, c->stream));
+            MRT_HIP(c, hipStreamSynchronize(c->stream));
+            c->fast.n_slots = (int)fslots;
+            c->fast.coords_ok = fcoords ? 1 : 0;
+            c->fast.stack_entries = fstack;
+            c->fast.ok = true;
+            stage("second tree packed");
+        }
+    }
     c->has_scene = true;
     c->cost_shape = 0;          // tile costs of the previous scene say nothing about this one
     ++c->scene_serial;
@@ -1047,6 +1145,20 @@ int mrt_get_tile_schedule(mrt_ctx* c, uint64_t out[2]) {
         MRT_HIP(c, hipMemcpy(&v, c->last_counters + kOrderCountSlot, sizeof v, hipMemcpyDeviceToHost));
         out[1] = v;
     }
+    return MRT_OK;
+}
+
+int mrt_get_second_tree_use(mrt_ctx* c, uint64_t out[2]) {
+    if (!c || !out) return MRT_E_ARG;
+    MRT_HIP(c, hipSetDevice(c->device));
+    out[0] = out[1] = 0;
+    if (!c->launched || !c->last_two_trees) return MRT_OK;
+    MRT_HIP(c, hipEventSynchronize(c->last_done));
+    if (int rc = counters_still_ours(c)) return rc;
+    unsigned long long v = 0;
+    MRT_HIP(c, hipMemcpy(&v, c->last_counters + kRedoCountSlot, sizeof v, hipMemcpyDeviceToHost));
+    out[0] = 1;
+    out[1] = v;
     return MRT_OK;
 }
 

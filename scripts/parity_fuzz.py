@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Random-pose parity campaign: GPU frames (both shaders, through the C ABI) against the CPU oracle for many random
 cameras in and around the default scene, random light positions, random sample grids.  Prints a summary line;
-exit status 1 on the first mismatch beyond the parity bar.  usage: parity_fuzz.py [--gpu-tree] [poses] [seed]"""
+exit status 1 on the first mismatch beyond the parity bar.  usage: parity_fuzz.py [--gpu-tree | --two-trees] [poses] [seed]
+--two-trees: scenes are uploaded with mrt_scene_upload_lbvh_exact (the recursive shader walks the GPU-built tree); the bar is the same."""
 import os
 import sys
 
@@ -41,7 +42,7 @@ def soups(n_scenes, seed):
         ora.add_scene(s)
         ora.build_bvh()
         ora.set_threads(16)
-        rt.build_bvh(s)
+        rt.build_bvh(s, lbvh="exact" if TWO_TREES else False)
         nl = int(rng.integers(0, 4))
         L = np.zeros((nl, 7), np.float32)
         L[:, :3] = rng.uniform([-20, -3, -45], [20, 8, 0], (nl, 3))
@@ -67,10 +68,17 @@ def soups(n_scenes, seed):
     return 0
 
 
+TWO_TREES = False
+
+
 def main():
     gpu_tree = "--gpu-tree" in sys.argv      # the clustered tree built on the GPU instead of the reference's: differences are counted, not fatal
     if gpu_tree:
         sys.argv.remove("--gpu-tree")
+    global TWO_TREES
+    if "--two-trees" in sys.argv:            # mrt_scene_upload_lbvh_exact: the recursive shader walks the GPU-built tree; everything must still be identical
+        sys.argv.remove("--two-trees")
+        TWO_TREES = True
     if len(sys.argv) > 1 and sys.argv[1] == "--soups":
         return soups(int(sys.argv[2]) if len(sys.argv) > 2 else 20, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     n_poses = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -86,9 +94,11 @@ def main():
     sizes = [(256, 192), (320, 200), (128, 128), (512, 64)]
     rts = {s: Raytracer(s[0], s[1], device=0) for s in sizes}
     for rt in rts.values():
-        rt.build_bvh(scene, lbvh=gpu_tree)
+        rt.build_bvh(scene, lbvh="exact" if TWO_TREES else gpu_tree)
     worst = 0.0
     rays = id_diffs = px_diffs = frames_off = 0
+    by_mode = {0: [0, 0], 1: [0, 0]}
+    second = [0, 0]
     for i in range(n_poses):
         W, H = sizes[i % len(sizes)]
         rt = rts[(W, H)]
@@ -113,6 +123,7 @@ def main():
                 b = ref["fb"].view(np.uint8).reshape(-1, 4).astype(np.int16)
                 e = int((np.abs(a - b).max(axis=1) > 1).sum()) if mode == 1 else int((fb != ref["fb"]).sum())
                 id_diffs += d; px_diffs += e; frames_off += (d > 0 or e > 0)
+                by_mode[mode][0] += d; by_mode[mode][1] += e
                 continue
             if not np.array_equal(ids, ref["ids"]):
                 print("pose %d mode %d: %d hit ids differ (pos %s target %s)" % (i, mode, int((ids != ref["ids"]).sum()), pos, target))
@@ -125,9 +136,15 @@ def main():
                 print("pose %d mode %d: pixels differ (%.5f beyond 1/255; pos %s target %s)" % (i, mode, frac, pos, target))
                 return 1
             c = rt.ray_counts()
+            if TWO_TREES and mode == 1:
+                walked, again = rt.second_tree_use()
+                second[0] += walked; second[1] += again
+    if TWO_TREES:
+        print("two trees: %d of %d recursive frames walked the second tree, %d rays traced again through the first" % (second[0], n_poses, second[1]))
     if gpu_tree:
         print("parity_fuzz with the GPU-built tree: %d poses x 2 shaders, %d primary rays: %d hit ids and %d pixels (packet: at all, recursive: beyond 1/255) "
-              "differ from the oracle's, in %d frames" % (n_poses, rays, id_diffs, px_diffs, frames_off))
+              "differ from the oracle's, in %d frames; packet shader %d ids %d pixels, recursive shader %d ids %d pixels%s" %
+              (n_poses, rays, id_diffs, px_diffs, frames_off, by_mode[0][0], by_mode[0][1], by_mode[1][0], by_mode[1][1], ""))
         return 0
     print("parity_fuzz: %d poses x 2 shaders: hit ids identical, packet pixels identical, worst recursive fraction beyond 1/255: %.6f" % (n_poses, worst))
     return 0
