@@ -615,13 +615,15 @@ __device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, 
 // One step of a team's agreement on the nearest hit: the running candidate {t, j} (distance, member that found it)
 // against the candidate of the lane the DPP pattern pairs this lane with; the nearer wins, the lower member on a tie
 // (it tested the earlier triangle: raytracer.cpp:1336-1344 keeps the first of two equal distances).
+// close (optional): set when the two candidates are different triangles within 16 units in the last place of each other.
 template <int DPP>
-__device__ __forceinline__ void team_min_step(float& t, int& j) {
+__device__ __forceinline__ void team_min_step(float& t, int& j, bool* close = nullptr) {
     // (the members of a team are active together; a lane whose partner were not would see its own candidate)
     const int ti = __builtin_bit_cast(int, t);
     const float to = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ti, ti, DPP, 0xf, 0xf, false));
     const int jo = __builtin_amdgcn_update_dpp(j, j, DPP, 0xf, 0xf, false);
     const bool take = (to < t) || (to == t && jo < j);
+    if (close) *close = *close || (jo != j && (uint32_t)(__float_as_int(to) - __float_as_int(t)) + 16u <= 32u);
     t = take ? to : t;
     j = take ? jo : j;
 }
@@ -633,7 +635,6 @@ __device__ __forceinline__ void team_min_step(float& t, int& j) {
 template <bool TEAM = false, bool EXACT = false, class SC, typename STP>
 __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool coords_ok, f3 O, f3 D, bool skip_ok, float& t, Hit& h, STP stack, Watch& wd,
                                                  int lane = 0, bool* unsure = nullptr) {
-    static_assert(!(TEAM && EXACT), "tiles of such a scene are not handed out in sixteenths");
     const Tie tie{sc.place, EXACT ? unsure : nullptr};
     h.tri = -1;
     if (n_tris == 0) return false;
@@ -697,18 +698,21 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
                 static_assert(MRT_LEAF_CHUNK == 16, "a team is the 16 lanes of a DPP row");
                 const uint32_t j = (uint32_t)lane & 15u;
                 const int tri_before = h.tri;
-                if (j < n_now) tri_test<false>(sc.tri_a(first + j), sc.tri_b(first + j), sc.tri_c(first + j), O, D, t, h, wd, Tie{sc.place});
+                if (j < n_now) tri_test<false>(sc.tri_a(first + j), sc.tri_b(first + j), sc.tri_c(first + j), O, D, t, h, wd, tie);
                 if (__any(h.tri != tri_before)) {   // a member has a new hit: nearer, or equally far and earlier in the reference's order
                     float tw = t;
                     // what decides between members: the distance, then the kept triangle's place in the reference's order
-                    // (a member without a new hit holds the old one: equal in all, and never better than a new one)
-                    int jw = h.tri >= 0 ? (int)sc.place[h.tri].x : 0x7fffffff;
-                    team_min_step<0xB1>(tw, jw);     // quad_perm [1,0,3,2]
-                    team_min_step<0x4E>(tw, jw);     // quad_perm [2,3,0,1]
-                    team_min_step<0x141>(tw, jw);    // row_half_mirror
-                    team_min_step<0x140>(tw, jw);    // row_mirror
+                    // (a member without a new hit holds the old one: equal in all, and never better than a new one).
+                    // EXACT: the triangle's number stands in for the place; candidates that near each other make the
+                    // ray unsure anyway (hit_is_the_references).
+                    auto rank = [&](int tri) { return tri < 0 ? 0x7fffffff : (EXACT ? tri : (int)sc.place[tri].x); };
+                    int jw = rank(h.tri);
+                    team_min_step<0xB1>(tw, jw, EXACT ? unsure : nullptr);     // quad_perm [1,0,3,2]
+                    team_min_step<0x4E>(tw, jw, EXACT ? unsure : nullptr);     // quad_perm [2,3,0,1]
+                    team_min_step<0x141>(tw, jw, EXACT ? unsure : nullptr);    // row_half_mirror
+                    team_min_step<0x140>(tw, jw, EXACT ? unsure : nullptr);    // row_mirror
                     // the members that hold the winning triangle are asked for it (they hold the same u and v: same arithmetic)
-                    const int mine = h.tri >= 0 ? (int)sc.place[h.tri].x : 0x7fffffff;
+                    const int mine = rank(h.tri);
                     const unsigned long long holders = (__ballot(t == tw && mine == jw) >> (lane & 48)) & 0xffffull;
                     const int from = (lane & 48) | (__ffsll((long long)holders) - 1);
                     t = tw;
@@ -745,6 +749,7 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
     if constexpr (EXACT) {
         bool undecided;
         if (h.tri >= 0 && !hit_is_the_references(sc.leaf_box, h.tri, O, D, t, true, undecided)) *unsure = true;
+        if constexpr (TEAM) *unsure = ((__ballot(*unsure) >> (lane & 48)) & 0xffffull) != 0;       // the members carry one ray
     }
     return h.tri >= 0;
 }
@@ -764,7 +769,6 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
 template <bool TEAM = false, bool EXACT = false, class SC>
 __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coords_ok, f3 O, f3 D, bool take_part, bool skip_ok, int lane, Watch& wd,
                                               bool* unsure = nullptr) {
-    static_assert(!(TEAM && EXACT), "tiles of such a scene are not handed out in sixteenths");
     if (n_tris == 0) return false;
     const v4f root0 = sc.node(0), root1 = sc.node(1);
     float tn;
@@ -803,7 +807,7 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
                 // member j of a team tests triangles j, j + 16, ... of the leaf; one member's hit is the team's answer
                 for (uint32_t k0 = first; k0 < first + count; k0 += 16u) {
                     const uint32_t k = k0 + ((uint32_t)lane & 15u);
-                    if (((m >> lane) & 1ull) && k < first + count && h.tri < 0) tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd, Tie{nullptr});
+                    if (((m >> lane) & 1ull) && k < first + count && h.tri < 0) { tri_test<false>(sc.tri_a(k), sc.tri_b(k), sc.tri_c(k), O, D, t, h, wd, Tie{nullptr}); vet(); }
                     const unsigned long long hits = __ballot(h.tri >= 0);
                     if ((hits >> (lane & 48)) & 0xffffull) h.tri = 0;
                     if (!__any(h.tri < 0 && ((m >> lane) & 1ull))) break;
@@ -855,6 +859,7 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
             if (ml) work.push(lane, wbits(l0), wbits(l1), ml);
         }
     }
+    if constexpr (EXACT && TEAM) *unsure = ((__ballot(*unsure) >> (lane & 48)) & 0xffffull) != 0;       // the members carry one ray
     return h.tri >= 0;
 }
 
@@ -997,7 +1002,7 @@ __device__ __forceinline__ void direct_light(const SC& sc, const SceneDev& S, bo
         bool occluded = occluded_wave<TEAM, EXACT>(sc, S.n_tris, S.coords_ok != 0, hit, L, lit, not_grazing(L, s.normal), lane, wd, &unsure);
         if constexpr (EXACT) {
             if (__any(unsure)) {          // Raytracer::IsOccluded itself (raytracer.cpp:414-418) on the reference's tree
-                count_retraced(wd, unsure);
+                count_retraced(wd, unsure && (!TEAM || (lane & 15) == 0));
                 if (unsure) {
                     float tt = INFINITY;
                     Hit hh;
@@ -1072,7 +1077,7 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
         if (tracing) isHit = traverse_nearest<TEAM, EXACT>(sc, S.n_tris, S.coords_ok != 0, O, D, skip_ok, t, h, stack, wd, lane, &unsure);
         if constexpr (EXACT) {
             if (__any(unsure)) {          // not certainly the reference's result: BVH::Traverse itself on the reference's tree
-                count_retraced(wd, unsure);
+                count_retraced(wd, unsure && (!TEAM || (lane & 15) == 0));
                 if (unsure) {
                     t = tmax;
                     isHit = traverse_nearest<false, false>(sc.ref, S.n_tris, S.ref_coords_ok != 0, O, D, true, t, h, stack, wd);
@@ -1183,7 +1188,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // EXACT (recursive shader, whole tiles): sc is another tree than the reference's (hit_is_the_references).
 template <int MODE, bool OBJ, bool TEAM = false, bool EXACT = false, class SC, typename STP>
 __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, const FrameDev& F, int tile, int lane, STP stack, int sub = 0) {
-    static_assert(!EXACT || (MODE == 1 && !TEAM), "only whole tiles of the recursive shader");
+    static_assert(!EXACT || MODE == 1, "only the recursive shader");
     // A sixteenth of a tile is four pixels for 64 lanes: every pixel gets a TEAM of 16 lanes (one DPP row) that all
     // carry the pixel's ray.  They walk the tree side by side (same ray, same decisions) and share out the triangles of
     // a leaf among themselves (traverse_nearest), which is what shortens the walk of a single ray tree; member 0 of a
@@ -1508,7 +1513,7 @@ __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_t
     MRT_LDS v4f* l_b = l_a + n_tri;
     MRT_LDS v2f* l_c = (MRT_LDS v2f*)(l_b + n_tri);
     MRT_LDS v4u* l_g = (MRT_LDS v4u*)(l_c + n_tri + (n_tri & 1u));
-    const uint32_t n_groups = (n_tri + 3u) / 4u;
+    const uint32_t n_groups = S.triG ? (n_tri + 3u) / 4u : 0u;       // (a scene without group boxes leaves their room to nodes and stacks)
     MRT_LDS uint16_t* l_stacks = (MRT_LDS uint16_t*)(l_g + n_groups);
     {
         const v4f* gn = reinterpret_cast<const v4f*>(S.nodes);
@@ -1556,8 +1561,10 @@ __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_t
         const uint32_t entry = F.tile_order ? F.tile_order[pos] : (uint32_t)pos;
         const int tile = (int)(entry & 0xffffffu), sub = (int)(entry >> 24);
         const unsigned long long t0 = __builtin_readcyclecounter();
-        if constexpr (EXACT) render_tile<MODE, false, false, true>(sc, S, F, tile, lane, stack);
-        else if (MODE == 1 && sub != 0) render_tile<MODE, false, MODE == 1>(sc, S, F, tile, lane, stack, sub);
+        if constexpr (EXACT) {
+            if (sub != 0) render_tile<MODE, false, true, true>(sc, S, F, tile, lane, stack, sub);
+            else render_tile<MODE, false, false, true>(sc, S, F, tile, lane, stack);
+        } else if (MODE == 1 && sub != 0) render_tile<MODE, false, MODE == 1>(sc, S, F, tile, lane, stack, sub);
         else render_tile<MODE, false>(sc, S, F, tile, lane, stack);
         if (F.tile_cost && lane == 0) {
             const unsigned long long dt = __builtin_readcyclecounter() - t0;
@@ -1803,11 +1810,11 @@ __global__ __launch_bounds__(64) void trace_rays_kernel(SceneDev S, int n_rays, 
 // ---------------------------------------------------------------------------------------
 // Host-callable launchers (used by the C ABI in mrt_api.cpp)
 // ---------------------------------------------------------------------------------------
-size_t resident_scene_bytes(int n_node_slots, int n_tris) {
-    return (size_t)n_node_slots * 32 + (size_t)n_tris * 40 + ((n_tris & 1) ? 8 : 0) + (size_t)((n_tris + 3) / 4) * 16;
+size_t resident_scene_bytes(int n_node_slots, int n_tris, bool groups) {
+    return (size_t)n_node_slots * 32 + (size_t)n_tris * 40 + ((n_tris & 1) ? 8 : 0) + (groups ? (size_t)((n_tris + 3) / 4) * 16 : 0);
 }
-size_t resident_lds_bytes(int n_node_slots, int n_tris, int stack_entries) {
-    return resident_scene_bytes(n_node_slots, n_tris) + (size_t)(kResidentThreads / 64) * stack_entries * 64 * sizeof(uint16_t);
+size_t resident_lds_bytes(int n_node_slots, int n_tris, int stack_entries, bool groups) {
+    return resident_scene_bytes(n_node_slots, n_tris, groups) + (size_t)(kResidentThreads / 64) * stack_entries * 64 * sizeof(uint16_t);
 }
 
 template <int MODE>
@@ -1836,7 +1843,7 @@ int resident_waves(int n_tiles, int n_cus, int threads, bool ordered) {
 
 template <int MODE, bool EXACT = false>
 static hipError_t launch_resident_mode(const SceneDev& S, const FrameDev& F, int n_cus, int threads, hipStream_t stream) {
-    const size_t lds = resident_lds_bytes(S.n_node_slots, S.n_tris, F.stack_entries);
+    const size_t lds = resident_lds_bytes(S.n_node_slots, S.n_tris, F.stack_entries, S.triG != nullptr);
     const int blocks = resident_blocks(F.n_tiles, n_cus, threads, F.tile_order != nullptr);
     threads = std::max(64, std::min(kResidentThreads, threads / 64 * 64));
     FrameDev Fq = F;

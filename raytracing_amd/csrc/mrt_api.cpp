@@ -31,7 +31,7 @@ hipError_t launch_order_tiles(uint32_t* cost, uint32_t* state, uint32_t* packed,
                               float budget_frac, int split_keys, size_t capacity, unsigned long long* n_entries,
                               uint32_t* spread_a, uint32_t* spread_b, int tiles_x, int radius, float share, hipStream_t stream);
 int resident_waves(int n_tiles, int n_cus, int threads, bool ordered);
-size_t resident_lds_bytes(int n_node_slots, int n_tris, int stack_entries);
+size_t resident_lds_bytes(int n_node_slots, int n_tris, int stack_entries, bool groups);
 hipError_t launch_trace_packets(const SceneDev& S, int n_packets, const float* O, const float* D, const float* rD,
                                 float* t, int32_t* tri, float* u, float* v, unsigned long long* flag, hipStream_t stream);
 hipError_t launch_trace_rays(const SceneDev& S, int n_rays, int stack_entries, const float* O, const float* D,
@@ -372,7 +372,7 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
         if (same_shape) {
             // expensive tiles of the recursive shader may be listed as sixteenths (kernels.hip: tile_order_kernel); the packet
             // traversal needs all 64 rays of a tile in one wave, and a sample grid is resolved across the tile's lanes
-            const bool allow_split = mode == (int)MRT_MODE_RECURSIVE && g == 1 && !two_trees;
+            const bool allow_split = mode == (int)MRT_MODE_RECURSIVE && g == 1;
             const int threads = env_int("MRT_RESIDENT_THREADS", kResidentThreads);
             // A camera that has moved since the frame the costs come from: what was expensive there is expensive a few
             // tiles further on here, so the order also looks at the costs within 4 % of the frame's width of a tile.
@@ -851,7 +851,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     c->scene.coords_ok = coords_ok ? 1 : 0;
     // LDS residency: nodes + triangles + 16 per-lane stacks must fit one CU's LDS, node indices 16 bits
     c->resident = B.n_tris > 0 && slots < 65536 &&
-                  resident_lds_bytes((int)slots, (int)B.n_tris, c->stack_entries) + 256 <= (size_t)kLdsBudget;
+                  resident_lds_bytes((int)slots, (int)B.n_tris, c->stack_entries, true) + 256 <= (size_t)kLdsBudget;
     c->resident = c->resident && env_int("MRT_RESIDENT", 1) != 0;      // 0 forces the global-memory kernel
     c->fast.ok = false;
     if (source == TreeSource::LbvhExact && B.n_tris > 0) {
@@ -863,13 +863,13 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
         int fstack = 0;
         bool fits = false;
         const int first_cost = env_int("MRT_SECOND_TREE_COST", 0);
-        for (float inner_cost : {first_cost > 0 ? (float)first_cost * 0.1f : 1.5f, 2.5f, 4.0f, 6.0f, 10.0f}) {
+        for (float inner_cost : {first_cost > 0 ? (float)first_cost * 0.1f : 1.5f, 2.0f, 2.5f, 3.0f, 3.5f, 4.0f, 5.0f, 6.0f, 8.0f, 12.0f, 20.0f}) {
             if (!build_lbvh_device(T, c->stream, err, inner_cost)) return fail(c, MRT_E_HIP, err);
             fslots = (size_t)T.pool_ptr + 1;
             fstack = std::max(T.max_depth + 2, c->stack_entries);        // the waves' stacks serve walks of either tree
-            fits = fstack <= kStackDepth && fslots < 65536 && resident_lds_bytes((int)fslots, (int)T.n_tris, fstack) + 256 <= (size_t)kLdsBudget;
+            fits = fstack <= kStackDepth && fslots < 65536 && resident_lds_bytes((int)fslots, (int)T.n_tris, fstack, false) + 256 <= (size_t)kLdsBudget;
             if (timing) fprintf(stderr, "mrt_scene_upload: second tree at inner cost %.1f: %zu node slots, %u triangles, stack %d, LDS %zu of %d bytes\n", inner_cost, fslots,
-                                T.n_tris, fstack, resident_lds_bytes((int)fslots, (int)T.n_tris, fstack) + 256, kLdsBudget);
+                                T.n_tris, fstack, resident_lds_bytes((int)fslots, (int)T.n_tris, fstack, false) + 256, kLdsBudget);
             if (fits) break;
         }
         stage("second tree (GPU)");
