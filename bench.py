@@ -33,7 +33,9 @@ Rank 0 prints one JSON line.  Besides the contract's keys it carries
                    memory, divergent traversal);
   c5_raster_1m_4k -- the rasterizer path on the same soup, device-resident frame;
   c2_800x600    -- the headline scene and shader at the reference's own window size (and at 512x512);
-  gpu_built_tree -- the headline workload on the tree built on the GPU instead of the reference's;
+  reference_tree_only -- the headline step with the scene uploaded by mrt_scene_upload (the reference's tree alone);
+  second_tree   -- how many rays of the headline frame had to be traced again through the reference's tree;
+  gpu_built_tree -- the headline workload on the tree built on the GPU alone (mrt_scene_upload_lbvh);
   c3_recursive  -- the soup through the recursive shader (background only, as in the reference).
 Every one of them carries a `roofline` object.  The reference algorithm's test counts of the configurations the
 CPU oracle cannot render inside a benchmark run (8K / 16 spp, 1 M triangles) are read from
@@ -78,7 +80,7 @@ class Workload:
     for a transfer that could only begin when the frame before it had ended."""
 
     def __init__(self, name, scene, width, height, mode, grid, cam, rank, world, torch, dist, split="frames", rt=None, device="cuda",
-                 exchange="native"):
+                 exchange="native", tree=False):
         from raytracing_amd.multigpu import NativeExchange, PartGather
         self.name, self.W, self.H, self.mode, self.grid, self.cam = name, width, height, mode, grid, cam
         self.rank, self.world, self.torch, self.dist, self.split = rank, world, torch, dist, split
@@ -89,7 +91,9 @@ class Workload:
         if rt is None:
             from raytracing_amd import Raytracer
             rt = Raytracer(width, height, device=torch.cuda.current_device())
-            rt.build_bvh(scene)
+            # tree: False = mrt_scene_upload (the reference's tree alone), "exact" = mrt_scene_upload_lbvh_exact (the recursive
+            # shader walks a second, GPU-built tree and reports the reference's results), True = mrt_scene_upload_lbvh
+            rt.build_bvh(scene, lbvh=tree)
         self.rt = rt
         self.events, self.pending, self.i = [], [], 0
         self.inflight = {}                 # split == "frames": step index -> transfers that read that step's buffer
@@ -399,15 +403,20 @@ def main():
 
     out, threads = {}, min(16, host_cpus()["cpus_allowed"])
     if world == 1:
-        head = Workload("c2", scene, W, H, MODE_RECURSIVE, 1, cam, rank, world, torch, dist, split="frames")
+        head = Workload("c2", scene, W, H, MODE_RECURSIVE, 1, cam, rank, world, torch, dist, split="frames", tree="exact")
         res = head.run(args.steps, args.warmup)
+        walked, again = head.rt.second_tree_use()
+        assert walked, "the headline frame did not walk the scene's second tree"
         out = {
             "metric": metric,
             "value": round(res["mrays_per_s"], 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(res["ms_per_step"], 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "default maze scene (2120 triangles, 1 light), 1920x1080, recursive reflection/refraction shader, "
-                                   "default camera; one frame per step, device-resident framebuffer",
+                                   "default camera; one frame per step, device-resident framebuffer; scene uploaded with "
+                                   "mrt_scene_upload_lbvh_exact: the rays walk a second, GPU-built tree held in LDS and every result is the "
+                                   "reference tree's (hit ids, pixels and ray counts identical to mrt_scene_upload's; `reference_tree_only` "
+                                   "is the same step through that call)",
                        "rays_per_frame": res["rays_per_step"], "rays_per_step": res["rays_per_step"],
                        "primary": res["primary"], "shadow": res["shadow"], "secondary": res["secondary"], "resolution": [W, H],
                        "multi_gpu": "with N > 1 the step is the 8K / 16 spp frame split across the ranks (c4_8k_16spp here is its N = 1 point)"},
@@ -415,11 +424,24 @@ def main():
         g2 = golden["c2_maze_1080p_recursive"]
         assert g2["counters"]["primary_rays"] + g2["counters"]["shadow_rays"] + g2["counters"]["secondary_rays"] == res["rays_per_step"], \
             "device ray counters disagree with the reference algorithm"
-        out["roofline"] = valu_roofline(flops_of(g2["counters"]), res["kernel_ms"], "render_tiles_resident<recursive>", **traffic_of("c2"),
+        out["second_tree"] = {"walked": bool(walked), "rays_traced_again_through_the_reference_tree_per_frame": int(again),
+                              "what": "mrt_get_second_tree_use after the last frame: a ray whose result from the second tree cannot be shown to be "
+                                      "the reference's (another triangle as near to within rounding, or the hit triangle's leaf box of the "
+                                      "reference's tree missed by the reference's arithmetic) is traced again through the reference's tree"}
+        out["roofline"] = valu_roofline(flops_of(g2["counters"]), res["kernel_ms"], "render_tiles_resident<recursive, second tree>", **traffic_of("c2"),
                                         hbm={"algorithmic_bytes_per_launch": 4 * W * H, "achieved_GBps": round(4 * W * H / (res["kernel_ms"] * 1e-3) / 1e9, 2), "peak_GBps": 8000})
         got = head.frame()
         out["parity"] = {"frame_hash_equals_oracle": _fbsum(got) == g2["fbsum"]}
         assert out["parity"]["frame_hash_equals_oracle"], "the headline frame differs from the oracle's"
+        # the same step through mrt_scene_upload: the reference's tree alone (what `value` was measured on before the second tree)
+        ref_only = Workload("c2ref", scene, W, H, MODE_RECURSIVE, 1, cam, rank, world, torch, dist, split="frames", tree=False)
+        rr = ref_only.run(args.steps, args.warmup)
+        assert rr["rays_per_step"] == res["rays_per_step"]
+        out["reference_tree_only"] = {"value": round(rr["mrays_per_s"], 3), "unit": "Mrays/s", "ms_per_step": round(rr["ms_per_step"], 5),
+                                      "kernel_ms": round(rr["kernel_ms"], 5), "frame_identical_to_the_headline_frame": bool(np.array_equal(ref_only.frame(), got)),
+                                      "roofline": valu_roofline(flops_of(g2["counters"]), rr["kernel_ms"], "render_tiles_resident<recursive>")}
+        assert out["reference_tree_only"]["frame_identical_to_the_headline_frame"]
+        del ref_only
         if not args.no_cpu:
             ora = oracle_work_and_baseline(scene, W, H, MODE_RECURSIVE, cam, threads, args.cpu_seconds)
             assert ora["rays"] == res["rays_per_step"] and ora["counters"] == g2["counters"]
@@ -524,9 +546,14 @@ def main():
         import oracle_lib
         small = {}
         for sw, sh in ((800, 600), (512, 512)):
-            wl = Workload("c2small", scene, sw, sh, MODE_RECURSIVE, 1, cam, rank, world, torch, dist)
+            wl = Workload("c2small", scene, sw, sh, MODE_RECURSIVE, 1, cam, rank, world, torch, dist, tree="exact")
             rs = wl.run(args.steps, args.warmup)
             tiles, handed = wl.rt.tile_schedule()
+            assert wl.rt.second_tree_use()[0]
+            wr = Workload("c2smallref", scene, sw, sh, MODE_RECURSIVE, 1, cam, rank, world, torch, dist, tree=False)
+            rsr = wr.run(args.steps, args.warmup)
+            assert np.array_equal(wr.frame(), wl.frame())
+            del wr
             o = oracle_lib.Oracle()
             o.add_scene(scene)
             o.build_bvh()
@@ -541,14 +568,16 @@ def main():
             small["%dx%d" % (sw, sh)] = {"value": round(rs["mrays_per_s"], 3), "unit": "Mrays/s", "ms_per_step": round(rs["ms_per_step"], 5),
                                          "kernel_ms": round(rs["kernel_ms"], 5), "rays_per_frame": rs["rays_per_step"],
                                          "tiles": tiles, "tiles_in_sixteenths": (handed - tiles) // 15,
+                                         "reference_tree_only_ms_per_step": round(rsr["ms_per_step"], 5),
                                          "pixels_different_from_oracle": int((a8 != b8).any(axis=1).sum()),
-                                         "roofline": valu_roofline(flops_of(k), rs["kernel_ms"], "render_tiles_resident<recursive>")}
+                                         "roofline": valu_roofline(flops_of(k), rs["kernel_ms"], "render_tiles_resident<recursive, second tree>")}
             del wl
-        out["c2_800x600"] = dict(small["800x600"], workload="the headline scene and shader at the reference's own window size, 800x600 (game.h:3-4); "
+        out["c2_800x600"] = dict(small["800x600"], workload="the headline scene and shader at the reference's own window size, 800x600 (game.h:3-4), uploaded like the "
+                                 "headline's (mrt_scene_upload_lbvh_exact; `reference_tree_only_ms_per_step`: through mrt_scene_upload, identical frame); "
                                  "`also_512x512`: the same at 512x512", also_512x512=small["512x512"])
-        # The headline workload on the tree built on the GPU (mrt_scene_upload_lbvh) instead of the reference's own: never `value`,
-        # because which triangle is named on an exact distance tie follows the tree (one frame in ninety of a random-pose campaign
-        # had a pixel that differed); this frame is compared with the oracle's like every other.
+        # The headline workload on the tree built on the GPU ALONE (mrt_scene_upload_lbvh: the tree in global memory, no check against
+        # the reference's): never `value`, because which triangle is named on an exact distance tie follows the tree (one frame in
+        # ninety of a random-pose campaign had a pixel that differed); this frame is compared with the oracle's like every other.
         from raytracing_amd import Raytracer
         rt_gpu = Raytracer(W, H, device=torch.cuda.current_device())
         t0 = time.perf_counter()
@@ -573,7 +602,7 @@ def main():
         del c4
     if not args.no_extra and world > 1:
         # N whole 1080p recursive frames per step, one per rank, gathered on rank 0 (what a frame loop does with frames too small to cut)
-        fr = Workload("c2", scene, W, H, MODE_RECURSIVE, 1, cam, rank, world, torch, dist, split="frames", exchange=args.exchange)
+        fr = Workload("c2", scene, W, H, MODE_RECURSIVE, 1, cam, rank, world, torch, dist, split="frames", exchange=args.exchange, tree="exact")
         rf = fr.run(args.steps, args.warmup)
         if rank == 0:
             out["c2_frames_per_rank"] = {"workload": "the N = 1 headline workload, one whole 1920x1080 recursive frame per rank and step, frames gathered on rank 0",
