@@ -21,7 +21,7 @@ pass() {  # config, pass name, counters...
   timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_${cfg}_$name -o pmc -- python3 $GRAFT_REPO_ROOT/scripts/config_probe.py $cfg 3 > $OUT/pmc_${cfg}_${name}_stdout.log 2>&1 || { echo "pmc pass $cfg $name failed"; tail -3 $OUT/pmc_${cfg}_${name}_stdout.log; return 1; }
   echo "pass $cfg $name done"
 }
-for cfg in c2 c2p c4 c3 c5; do
+for cfg in c2 c2r c2p c4 c3 c5; do
   pass $cfg sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD && \
   pass $cfg sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_THREAD_CYCLES_VALU && \
   pass $cfg fetch FETCH_SIZE && \

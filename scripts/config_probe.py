@@ -3,7 +3,8 @@
 per-configuration rocprofv3 passes of profiles/run_profile_r02.sh run.
 
     config_probe.py c2|c2p|c3|c4|c5 [frames] [move]       move: the eye moves a little every frame
-      c2  maze 1920x1080 recursive      c2p maze 1920x1080 packet       c4  maze 7680x4320, 4x4 samples, packet
+      c2  maze 1920x1080 recursive (uploaded with mrt_scene_upload_lbvh_exact, like bench.py's headline)
+      c2r the same through mrt_scene_upload      c2p maze 1920x1080 packet       c4  maze 7680x4320, 4x4 samples, packet
       c3  1,000,000-triangle soup 3840x2160 packet                      c5  the same soup through the rasterizer
 """
 import os
@@ -22,12 +23,12 @@ def main():
     import torch
     from raytracing_amd import Raytracer, scene_io
     maze = scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "maze.mrts"))
-    W, H, mode, grid, scene = {"c2": (1920, 1080, 1, 1, maze), "c2p": (1920, 1080, 0, 1, maze), "c4": (7680, 4320, 0, 4, maze),
+    W, H, mode, grid, scene = {"c2": (1920, 1080, 1, 1, maze), "c2r": (1920, 1080, 1, 1, maze), "c2p": (1920, 1080, 0, 1, maze), "c4": (7680, 4320, 0, 4, maze),
                                "c3": (3840, 2160, 0, 1, None), "c5": (3840, 2160, -1, 1, None)}[cfg]
     if scene is None:
         scene = scene_io.large_scene(maze)
     rt = Raytracer(W, H, device=0)
-    rt.build_bvh(scene)
+    rt.build_bvh(scene, lbvh="exact" if cfg == "c2" else False)
     cam = np.eye(4, dtype=np.float32).reshape(16)
     fb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
     st = torch.cuda.current_stream()
