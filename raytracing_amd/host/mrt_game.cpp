@@ -3,7 +3,7 @@
 // reports frame time and ray throughput the way the reference's overlay does (game.cpp:95-112).
 //
 //   mrt_game [--scene assets/maze.obj | scene.mrts] [--size W H] [--frames N]
-//            [--mode packet|recursive|depth|raster] [--spheres] [--pos x y z --lookat x y z]
+//            [--mode packet|recursive|depth|raster] [--spheres] [--one-tree] [--pos x y z --lookat x y z]
 //            [--out frame.ppm|frame.png] [--out-sequence prefix] [--overlay] [--dump-scene out.mrts] [--device N]
 //            [--script "W*30 RIGHT*10 O*5 U*3 SPACE*1" --dt 0.016] [--no-render] [--pipeline]
 //            [--ranks N --rank R --nccl-id FILE [--block B] [--spp-grid G]]  |  [--rehearse-ranks N]
@@ -13,6 +13,7 @@
 // between ray tracer and rasterizer).  --no-render runs the script only and prints the final state.
 // --mode depth is the BVH-depth view (raytracer.cpp:581-586; the script key T toggles it like game.cpp:73);
 // --spheres adds the two spheres Raytracer::Init creates (raytracer.cpp:404-412), which the reference never traces.
+// --one-tree uploads the scene with mrt_scene_upload (the reference's tree alone) instead of mrt_scene_upload_lbvh_exact.
 // --overlay draws the reference's frame-time / FPS lines into every frame (game.cpp:95-112), updated once per second of
 // frame time like there; --out-sequence writes every frame as prefix_0000.png, prefix_0001.png, ... (the stand-in for the
 // window the reference presents its Surface in, template.cpp:111-127).
@@ -148,7 +149,7 @@ int main(int argc, char** argv) {
     MultiOpts multi;
     std::string scene_file = "assets/maze.obj", mode = "packet", out, dump, script;
     float dt = 0.016f;
-    bool no_render = false, pipeline = false, overlay = false, spheres = false;
+    bool no_render = false, pipeline = false, overlay = false, spheres = false, one_tree = false;
     std::string sequence;
     int W = 800, H = 600, frames = 10, device = -1;       // game.h:3-4
     bool have_pose = false;
@@ -168,6 +169,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--pipeline")) pipeline = true;
         else if (!strcmp(argv[i], "--overlay")) overlay = true;
         else if (!strcmp(argv[i], "--spheres")) spheres = true;
+        else if (!strcmp(argv[i], "--one-tree")) one_tree = true;       // mrt_scene_upload instead of mrt_scene_upload_lbvh_exact
         else if (!strcmp(argv[i], "--out-sequence")) { need(1); sequence = argv[++i]; }
         else if (!strcmp(argv[i], "--ranks")) { need(1); multi.ranks = atoi(argv[++i]); }
         else if (!strcmp(argv[i], "--rank")) { need(1); multi.rank = atoi(argv[++i]); }
@@ -227,7 +229,7 @@ int main(int argc, char** argv) {
         auto t0 = std::chrono::steady_clock::now();
         if (!no_render) {
             raytracer.Init(&screen, device);                    // game.cpp:17-18
-            raytracer.BuildBVH(scene);                          // game.cpp:34
+            raytracer.BuildBVH(scene, !one_tree);               // game.cpp:34
             if (spheres) raytracer.SetObjects(objects);
             printf("BuildBVH + upload: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         }

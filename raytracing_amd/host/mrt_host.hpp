@@ -467,8 +467,10 @@ public:
         screen_ = screen;
         check(mrt_create(screen->GetWidth(), screen->GetHeight(), device, &ctx_), "mrt_create");
     }
-    // Raytracer::BuildBVH(meshList) (raytracer.cpp:670-673)
-    void BuildBVH(const Scene& scene) {
+    // Raytracer::BuildBVH(meshList) (raytracer.cpp:670-673).  second_tree: upload with mrt_scene_upload_lbvh_exact -- the
+    // reference's tree as ever, and beside it the GPU-built one that frames of the recursive shader walk with identical
+    // results (mrt.h); false: mrt_scene_upload, the reference's tree alone.
+    void BuildBVH(const Scene& scene, bool second_tree = true) {
         std::vector<mrt_mesh> meshes;
         for (const Mesh& m : scene.meshList) {
             if (m.tris() == 0) continue;       // a "usemtl" that no face follows leaves an empty mesh: nothing to trace
@@ -478,7 +480,8 @@ public:
         }
         std::vector<mrt_texture> textures;
         for (const Texture& t : scene.texList) textures.push_back(mrt_texture{t.indices.data(), t.palettes.data(), t.width, t.height});
-        check(mrt_scene_upload(ctx_, meshes.data(), (int)meshes.size(), textures.data(), (int)textures.size()), "mrt_scene_upload");
+        if (second_tree) check(mrt_scene_upload_lbvh_exact(ctx_, meshes.data(), (int)meshes.size(), textures.data(), (int)textures.size()), "mrt_scene_upload_lbvh_exact");
+        else check(mrt_scene_upload(ctx_, meshes.data(), (int)meshes.size(), textures.data(), (int)textures.size()), "mrt_scene_upload");
     }
     // m_Lights (raytracer.h:244): 7 floats per light {pos, colour in A,R,G,B order}
     void SetLights(const std::vector<float>& pos_argb7) {
