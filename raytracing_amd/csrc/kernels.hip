@@ -998,8 +998,9 @@ __device__ __forceinline__ void direct_light(const SC& sc, const SceneDev& S, bo
     for (int i = 0; i < S.n_lights; ++i) {
         const float4 lp = S.lights[2 * i];
         const f3 L = lit ? normalize(xyz(lp) - hit) : f3{0.0f, 0.0f, 1.0f};
-        bool unsure = false;
-        bool occluded = occluded_wave<TEAM, EXACT>(sc, S.n_tris, S.coords_ok != 0, hit, L, lit, not_grazing(L, s.normal), lane, wd, &unsure);
+        const bool off_plane = not_grazing(L, s.normal);
+        bool unsure = EXACT && lit && !off_plane;           // (such a shadow ray goes straight to the reference's tree)
+        bool occluded = occluded_wave<TEAM, EXACT>(sc, S.n_tris, S.coords_ok != 0, hit, L, lit && !unsure, off_plane, lane, wd, &unsure);
         if constexpr (EXACT) {
             if (__any(unsure)) {          // Raytracer::IsOccluded itself (raytracer.cpp:414-418) on the reference's tree
                 count_retraced(wd, unsure && (!TEAM || (lane & 15) == 0));
@@ -1073,8 +1074,9 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
         float t = tmax;
         bool isHit = false;
         MRT_PHASE_BEGIN(wd);
-        bool unsure = false;
-        if (tracing) isHit = traverse_nearest<TEAM, EXACT>(sc, S.n_tris, S.coords_ok != 0, O, D, skip_ok, t, h, stack, wd, lane, &unsure);
+        // (EXACT: a ray nearly in the plane of the surface it starts from -- see not_grazing -- goes straight to the reference's tree)
+        bool unsure = EXACT && tracing && !skip_ok;
+        if (tracing && !unsure) isHit = traverse_nearest<TEAM, EXACT>(sc, S.n_tris, S.coords_ok != 0, O, D, skip_ok, t, h, stack, wd, lane, &unsure);
         if constexpr (EXACT) {
             if (__any(unsure)) {          // not certainly the reference's result: BVH::Traverse itself on the reference's tree
                 count_retraced(wd, unsure && (!TEAM || (lane & 15) == 0));

@@ -19,12 +19,12 @@ pytestmark = pytest.mark.gpu
 W = H = 64
 
 
-def run_campaign(scene, n_walls, angles=grazing_cases.ANGLES, offsets=grazing_cases.OFFSETS, modes=(MODE_PACKET, MODE_RECURSIVE)):
+def run_campaign(scene, n_walls, angles=grazing_cases.ANGLES, offsets=grazing_cases.OFFSETS, modes=(MODE_PACKET, MODE_RECURSIVE), tree=False):
     """Renders every grazing camera on the GPU and with the oracle; returns (frames, frames whose hit ids differ,
     rays whose hit ids differ, recursive frames beyond the colour bar, packet frames whose pixels differ)."""
     bvh = binding.bvh_build_host(scene)
     rt = Raytracer(W, H, device=0)
-    rt.build_bvh(scene)
+    rt.build_bvh(scene, lbvh=tree)
     ora = oracle_lib.Oracle()
     ora.add_scene(scene)
     ora.build_bvh()
@@ -50,8 +50,11 @@ def run_campaign(scene, n_walls, angles=grazing_cases.ANGLES, offsets=grazing_ca
     return frames, bad_frames, bad_rays, bad_colour, bad_pixels
 
 
-def test_primary_rays_grazing_long_leaf_walls(maze_scene):
-    frames, bad_frames, bad_rays, bad_colour, bad_pixels = run_campaign(maze_scene, 8)
+@pytest.mark.parametrize("tree", [False, "exact"], ids=["reference's tree", "two trees"])
+def test_primary_rays_grazing_long_leaf_walls(maze_scene, tree):
+    """tree = "exact": the scene uploaded with mrt_scene_upload_lbvh_exact -- the recursive frames walk the second tree,
+    whose boxes are small where the reference's leaves are long."""
+    frames, bad_frames, bad_rays, bad_colour, bad_pixels = run_campaign(maze_scene, 8, tree=tree)
     assert frames > 1500
     assert bad_rays == 0, "hit ids differ on %d rays in %d of %d frames" % (bad_rays, bad_frames, frames)
     assert bad_pixels == 0 and bad_colour == 0
