@@ -72,6 +72,8 @@ struct SceneDev {
     const float4* ref_triA;
     const float4* ref_triB;
     const float2* ref_triC;
+    const float4* ref_triM;
+    const uint4* ref_triG;
     const uint2* ref_place;
     int ref_coords_ok;
 };
@@ -117,6 +119,9 @@ struct FrameDev {
     const float4* eye_nodes;
     const float4* eye_tri;
     const float4* eye_g;
+    // the same of a scene's second tree (SceneDev::leaf_box; no group boxes), for packet-path launches through it
+    const float4* eye_nodes2;
+    const float4* eye_tri2;
 };
 
 constexpr int kOrderCountSlot = 7;     // counters[7]: entries of the frame's tile order list (tile_order_kernel)

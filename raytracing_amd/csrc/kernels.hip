@@ -145,6 +145,12 @@ struct SceneGlobalEyeT : SceneGlobalT<G> {
     const v4f* eyeNodes; const v4f* eyeTri;
     const v4f* eyeG;      // [2g], [2g+1] = the group box's corners minus O (nullptr: no group boxes)
 };
+// A scene's second tree as the packet path of the one-wave-per-tile kernel sees it (no group boxes), with the
+// reference's own tree beside it (hit_is_the_references); GR: the reference's tree has group boxes.
+template <bool GR>
+struct SceneTwoTreesT : SceneGlobalEyeT<false> {
+    SceneGlobalEyeT<GR> ref;
+};
 struct SceneLds {
     static constexpr bool kPrefetchLeaf = true;     // request triangle k+1 before testing triangle k
     static constexpr bool kEyeRelative = false;
@@ -298,13 +304,25 @@ struct Tie {
 // (then the lane's shadow ray too goes through the reference's tree: direct_light).
 constexpr float kExactCull = 1.0f + 0x1p-10f;
 // undecided: a quotient of the leaf's box test is 0/0 (the ray runs inside a face of the box)
+// PACKET: the box test as the packet traversal computes it (raytracer.cpp:1372-1376: products with the ray's reciprocal
+// direction rD, passed in D's place; 0 * inf is its 0/0).  The argument is the same: a ray that passes the leaf's box
+// passes its ancestors', so every node on the way is entered for a ray no later than this one, and the leaf's
+// triangles are tested for every ray from that one on (raytracer.cpp:1445-1464).
+template <bool PACKET = false>
 __device__ __forceinline__ bool hit_is_the_references(const v4f* leaf_box, int tri, f3 O, f3 D, float T, bool nearest, bool& undecided) {
     const v4f lo = leaf_box[2 * (size_t)tri], hi = leaf_box[2 * (size_t)tri + 1];
-    const bool nan_x = D.x == 0.0f && (lo.x == O.x || hi.x == O.x), nan_y = D.y == 0.0f && (lo.y == O.y || hi.y == O.y),
-               nan_z = D.z == 0.0f && (lo.z == O.z || hi.z == O.z);
+    bool nan_x, nan_y, nan_z;
+    if (PACKET) {
+        nan_x = !(fabsf(D.x) < INFINITY) && (lo.x == O.x || hi.x == O.x); nan_y = !(fabsf(D.y) < INFINITY) && (lo.y == O.y || hi.y == O.y);
+        nan_z = !(fabsf(D.z) < INFINITY) && (lo.z == O.z || hi.z == O.z);
+    } else {
+        nan_x = D.x == 0.0f && (lo.x == O.x || hi.x == O.x); nan_y = D.y == 0.0f && (lo.y == O.y || hi.y == O.y);
+        nan_z = D.z == 0.0f && (lo.z == O.z || hi.z == O.z);
+    }
     undecided = nan_x || nan_y || nan_z;
     float tNear, tFar;
-    slab_terms((xyz(lo) - O) / D, (xyz(hi) - O) / D, tNear, tFar);
+    if (PACKET) slab_terms((xyz(lo) - O) * D, (xyz(hi) - O) * D, tNear, tFar);
+    else slab_terms((xyz(lo) - O) / D, (xyz(hi) - O) / D, tNear, tFar);
     bool ok = !undecided && (tFar >= tNear) && (tFar > 0);
     if (nearest) ok = ok && (tNear <= T || (uint32_t)(__float_as_int(tNear) - __float_as_int(T)) <= 8u);
     return ok;
@@ -498,8 +516,11 @@ __device__ __forceinline__ void walk_leaf_by_groups(const SC& sc, uint32_t first
 // child at once from the terms already computed.  Visiting a leaf tests every lane >= i
 // against every triangle of the leaf, in leaf order.
 // ---------------------------------------------------------------------------------------
-template <bool FINITE, class SC>
-__device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f3 rD, float& t, Hit& h, int lane, Watch& wd) {
+// EXACT: sc is another tree than the reference's (hit_is_the_references): boxes are dismissed by distance only when they
+// begin clearly beyond a ray's nearest hit so far, and near-equal candidates set the lane's `unsure`.
+template <bool FINITE, bool EXACT, class SC>
+__device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f3 rD, float& t, Hit& h, int lane, Watch& wd, bool* unsure) {
+    auto reach = [&]() { return EXACT ? t * kExactCull : t; };
     // box(i): node record i as the box tests want it; with the frame's eye-relative copy the subtraction of
     // the origin has already been done
     auto box = [&](uint32_t i) -> v4f {
@@ -531,7 +552,7 @@ __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f
         else { n0 = box(2 * node); n1 = box(2 * node + 1); }
         float tn, tf;
         terms(xyz(n0), xyz(n1), tn, tf);
-        const bool pass = slab_pass(tn, tf, t);
+        const bool pass = slab_pass(tn, tf, reach());
         unsigned long long mask = __ballot(pass) & (~0ull << f);
         if (mask == 0) continue;
         int i = __ffsll((long long)mask) - 1;
@@ -539,7 +560,7 @@ __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f
         for (;;) {                             // visit(node = {first,count}, firstActive = i)
             if (count != 0) {
                 if (lane >= i) {
-                    const Tie tie{sc.place};
+                    const Tie tie{sc.place, EXACT ? unsure : nullptr};
                     if (sc.has_groups() && count >= (uint32_t)MRT_GROUP_MIN) {
                         walk_leaf_by_groups<SC::kEyeRelative>(sc, first, count, O, rg, rg_ok, t, wd, [&](uint32_t k) {
                             MRT_TICK(wd, 10);
@@ -583,7 +604,7 @@ __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f
             terms(xyz(r0), xyz(r1), tnr, tfr);
             const bool right_first = lane_bcast(tnr, i) < lane_bcast(tnl, i);   // raytracer.cpp:1384
             work.push(lane, ((right_first ? L : R) << 6) | (uint32_t)i);
-            const bool p = right_first ? slab_pass(tnr, tfr, t) : slab_pass(tnl, tfl, t);
+            const bool p = right_first ? slab_pass(tnr, tfr, reach()) : slab_pass(tnl, tfl, reach());
             mask = __ballot(p) & (~0ull << i);
             if (mask == 0) break;
             i = __ffsll((long long)mask) - 1;
@@ -593,16 +614,16 @@ __device__ __forceinline__ void traverse_packet_impl(const SC& sc, f3 O, f3 D, f
     }
 }
 
-template <class SC>
-__device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, f3 D, f3 rD, float& t, Hit& h, int lane, Watch& wd) {
+template <bool EXACT = false, class SC>
+__device__ __forceinline__ void traverse_packet(const SC& sc, int n_tris, f3 O, f3 D, f3 rD, float& t, Hit& h, int lane, Watch& wd, bool* unsure = nullptr) {
     if (n_tris == 0) return;
     // With every 1/D component finite, (bound - O) * rD is never a NaN, and hardware min/max
     // then give the predicates the same values as glm's compare+select (up to the sign of a
     // zero, which no comparison sees).  A wave holding an axis-parallel ray (1/0 = inf) runs the
     // compare+select instance of the traversal.
     const bool finite = !__any(!(fabsf(rD.x) < INFINITY && fabsf(rD.y) < INFINITY && fabsf(rD.z) < INFINITY));
-    if (finite) traverse_packet_impl<true>(sc, O, D, rD, t, h, lane, wd);
-    else traverse_packet_impl<false>(sc, O, D, rD, t, h, lane, wd);
+    if (finite) traverse_packet_impl<true, EXACT>(sc, O, D, rD, t, h, lane, wd, unsure);
+    else traverse_packet_impl<false, EXACT>(sc, O, D, rD, t, h, lane, wd, unsure);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -983,10 +1004,10 @@ __device__ __forceinline__ Surf object_surface(const SceneDev& S, int k, f3 hit)
 // ray per light, starting exactly on the surface (no epsilon).  Must be called by all 64 lanes.
 // REMAKE_COLOUR: the surface colour is made again from the packed palette entry after every shadow traversal
 // instead of being kept in four registers across it (the packet kernel is compiled for 64 registers).
-// EXACT (stack: the lane's traversal stack): see hit_is_the_references.
-template <bool OBJ, bool REMAKE_COLOUR, bool TEAM = false, bool EXACT = false, class SC, typename STP = int>
+// EXACT: see hit_is_the_references.
+template <bool OBJ, bool REMAKE_COLOUR, bool TEAM = false, bool EXACT = false, class SC>
 __device__ __forceinline__ void direct_light(const SC& sc, const SceneDev& S, bool shade, const Surf& s, f3 hit, f4& finalColor,
-                                             int lane, uint32_t& n_shadow, Watch& wd, STP stack = STP()) {
+                                             int lane, uint32_t& n_shadow, Watch& wd) {
     const float lightStrength = shade ? 1.0f - (s.refr + s.refl) : 0.0f;
     const bool lit = shade && lightStrength > 0.0f;
     // the ambient term opens the sum; with REMAKE_COLOUR it is added when the first light's colour is at hand
@@ -1002,13 +1023,10 @@ __device__ __forceinline__ void direct_light(const SC& sc, const SceneDev& S, bo
         bool unsure = EXACT && lit && !off_plane;           // (such a shadow ray goes straight to the reference's tree)
         bool occluded = occluded_wave<TEAM, EXACT>(sc, S.n_tris, S.coords_ok != 0, hit, L, lit && !unsure, off_plane, lane, wd, &unsure);
         if constexpr (EXACT) {
-            if (__any(unsure)) {          // Raytracer::IsOccluded itself (raytracer.cpp:414-418) on the reference's tree
+            if (__any(unsure)) {          // those lanes' shadow rays once more, through the reference's tree
                 count_retraced(wd, unsure && (!TEAM || (lane & 15) == 0));
-                if (unsure) {
-                    float tt = INFINITY;
-                    Hit hh;
-                    occluded = traverse_nearest<false, false>(sc.ref, S.n_tris, S.ref_coords_ok != 0, hit, L, true, tt, hh, stack, wd);
-                }
+                const bool again = occluded_wave<false, false>(sc.ref, S.n_tris, S.ref_coords_ok != 0, hit, L, unsure, off_plane, lane, wd);
+                occluded = unsure ? again : occluded;
             }
         }
         if constexpr (OBJ) { if (lit && !occluded) occluded = objects_occlude(S, hit, L); }
@@ -1099,7 +1117,7 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
         }
         f4 finalColor = {0, 0, 0, 0};
         MRT_PHASE_BEGIN(wd);
-        direct_light<OBJ, false, TEAM, EXACT>(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd, stack);
+        direct_light<OBJ, false, TEAM, EXACT>(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
         MRT_PHASE_END(wd, 17);
         if (!tracing) continue;
         tracing = false;
@@ -1190,7 +1208,6 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 // EXACT (recursive shader, whole tiles): sc is another tree than the reference's (hit_is_the_references).
 template <int MODE, bool OBJ, bool TEAM = false, bool EXACT = false, class SC, typename STP>
 __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, const FrameDev& F, int tile, int lane, STP stack, int sub = 0) {
-    static_assert(!EXACT || MODE == 1, "only the recursive shader");
     // A sixteenth of a tile is four pixels for 64 lanes: every pixel gets a TEAM of 16 lanes (one DPP row) that all
     // carry the pixel's ray.  They walk the tree side by side (same ray, same decisions) and share out the triangles of
     // a leaf among themselves (traverse_nearest), which is what shortens the walk of a single ray tree; member 0 of a
@@ -1227,7 +1244,19 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
         const f3 rD = 1.0f / D;
         float t = 100000000;
         MRT_PHASE_BEGIN(wd);
-        traverse_packet(sc, S.n_tris, O, D, rD, t, h, lane, wd);
+        if constexpr (EXACT) {
+            bool unsure = false;
+            traverse_packet<true>(sc, S.n_tris, O, D, rD, t, h, lane, wd, &unsure);
+            bool undecided;
+            if (h.tri >= 0 && !hit_is_the_references<true>(sc.leaf_box, h.tri, O, rD, t, true, undecided)) unsure = true;
+            if (__any(unsure)) {          // the packet once more, through the reference's tree: what a ray of a packet tests depends on the others
+                count_retraced(wd, unsure);
+                t = 100000000; h.tri = -1; h.u = 0; h.v = 0;
+                traverse_packet(sc.ref, S.n_tris, O, D, rD, t, h, lane, wd);
+            }
+        } else {
+            traverse_packet(sc, S.n_tris, O, D, rD, t, h, lane, wd);
+        }
         MRT_PHASE_END(wd, 16);
         if constexpr (OBJ) trace_objects(S, O, D, t, h);
         const bool shade = h.tri != -1;
@@ -1240,7 +1269,7 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
         }
         f4 finalColor = {0, 0, 0, 0};
         MRT_PHASE_BEGIN(wd);
-        direct_light<OBJ, !OBJ>(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
+        direct_light<OBJ, !OBJ, false, EXACT>(sc, S, shade, s, hit, finalColor, lane, n_shadow, wd);
         MRT_PHASE_END(wd, 17);
         color = shade ? clamp01(finalColor) : MRT_BACKGROUND;
     } else {
@@ -1380,6 +1409,27 @@ __global__ __launch_bounds__(64, MODE == 0 ? MRT_PACKET_WAVES : MRT_RECURSIVE_WA
     } else {
         render_tile<MODE, OBJ>(global_scene<G>(S), S, F, tile, lane, (MRT_LDS uint32_t*)lds_stack + lane);
     }
+}
+
+// The packet path through a scene's second tree (S.nodes ... the second tree's, S.leaf_box and S.ref_* set; F.eye_*2 its
+// eye-relative copy, F.eye_* the reference tree's): render_tiles_global<0> with both trees at hand.
+template <bool GR>
+__global__ __launch_bounds__(64, MRT_PACKET_WAVES) void render_tiles_two_trees_packet(SceneDev S, FrameDev F) {
+    __shared__ uint32_t lds_stack[64];
+    const int lane = threadIdx.x;
+    const int b = (int)blockIdx.x, q = b / kXcds;
+    const int tile = ((q / kXcdRun) * kXcds + b % kXcds) * kXcdRun + q % kXcdRun;       // (as in render_tiles_global)
+    if (tile >= F.n_tiles) return;
+    SceneTwoTreesT<GR> sc;
+    sc.nodes = reinterpret_cast<const v4f*>(S.nodes); sc.triA = reinterpret_cast<const v4f*>(S.triA); sc.triB = reinterpret_cast<const v4f*>(S.triB);
+    sc.triC = reinterpret_cast<const v2f*>(S.triC); sc.triG = nullptr; sc.triM = reinterpret_cast<const v4f*>(S.triM); sc.place = nullptr;
+    sc.leaf_box = reinterpret_cast<const v4f*>(S.leaf_box);
+    sc.eyeNodes = reinterpret_cast<const v4f*>(F.eye_nodes2); sc.eyeTri = reinterpret_cast<const v4f*>(F.eye_tri2); sc.eyeG = nullptr;
+    sc.ref.nodes = reinterpret_cast<const v4f*>(S.ref_nodes); sc.ref.triA = reinterpret_cast<const v4f*>(S.ref_triA); sc.ref.triB = reinterpret_cast<const v4f*>(S.ref_triB);
+    sc.ref.triC = reinterpret_cast<const v2f*>(S.ref_triC); sc.ref.triG = reinterpret_cast<const v4u*>(S.ref_triG); sc.ref.triM = reinterpret_cast<const v4f*>(S.ref_triM);
+    sc.ref.place = S.ref_place;
+    sc.ref.eyeNodes = reinterpret_cast<const v4f*>(F.eye_nodes); sc.ref.eyeTri = reinterpret_cast<const v4f*>(F.eye_tri); sc.ref.eyeG = reinterpret_cast<const v4f*>(F.eye_g);
+    render_tile<0, false, false, true>(sc, S, F, tile, lane, (MRT_LDS uint32_t*)lds_stack + lane);
 }
 
 // The frame's eye-relative copy of the nodes and triangles (SceneGlobalEyeT): one thread per node record and
@@ -1872,11 +1922,17 @@ hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool re
     return mode == 0 ? launch_global_mode<0>(S, F, stream) : launch_global_mode<1>(S, F, stream);
 }
 
-// A frame of the recursive shader through a scene's second tree (S.leaf_box and S.ref_* set, S.nodes ... the second
-// tree's, resident; no analytic primitives).  F.stack_entries: enough for either tree.
-hipError_t launch_render_second_tree(const SceneDev& S, const FrameDev& F, int n_cus, int resident_threads, hipStream_t stream) {
+// A frame through a scene's second tree (S.leaf_box and S.ref_* set, S.nodes ... the second tree's; no analytic
+// primitives).  Recursive shader: the persistent kernel, the second tree in LDS, F.stack_entries enough for either tree.
+// Packet path: one wave per tile, both trees in global memory with their eye-relative copies (F.eye_*2, F.eye_*).
+hipError_t launch_render_second_tree(const SceneDev& S, const FrameDev& F, int mode, int n_cus, int resident_threads, hipStream_t stream) {
     if (F.n_tiles <= 0) return hipSuccess;
-    return launch_resident_mode<1, true>(S, F, n_cus, resident_threads, stream);
+    if (mode == 1) return launch_resident_mode<1, true>(S, F, n_cus, resident_threads, stream);
+    const int group = kXcds * kXcdRun;
+    const dim3 grid((unsigned)((F.n_tiles + group - 1) / group * group)), block(64);
+    if (S.ref_triG) hipLaunchKernelGGL((render_tiles_two_trees_packet<true>), grid, block, 0, stream, S, F);
+    else hipLaunchKernelGGL((render_tiles_two_trees_packet<false>), grid, block, 0, stream, S, F);
+    return hipGetLastError();
 }
 
 // group_pad: the padding of the scene's group boxes (mrt_scene_upload), also the distance from a triangle's plane

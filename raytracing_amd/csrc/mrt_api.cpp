@@ -22,7 +22,7 @@
 
 namespace mrt {
 hipError_t launch_render(const SceneDev& S, const FrameDev& F, int mode, bool resident, int n_cus, int resident_threads, hipStream_t stream);
-hipError_t launch_render_second_tree(const SceneDev& S, const FrameDev& F, int n_cus, int resident_threads, hipStream_t stream);
+hipError_t launch_render_second_tree(const SceneDev& S, const FrameDev& F, int mode, int n_cus, int resident_threads, hipStream_t stream);
 hipError_t launch_eye_relative(const SceneDev& S, const float eye[3], float group_pad, float4* eye_nodes, float4* eye_tri, float4* eye_g, hipStream_t stream);
 hipError_t launch_eye_groups(const SceneDev& S, const float eye[3], float group_pad, uint4* out, hipStream_t stream);
 hipError_t prepare_render_kernels();
@@ -131,10 +131,13 @@ struct mrt_ctx {
     DevBuf<uint4> d_triG;
     DevBuf<float4> d_triM;
     // mrt_scene_upload_lbvh_exact: a second, GPU-built tree over the same triangles, which frames of the recursive shader
-    // walk instead when it fits the LDS (kernels.hip: hit_is_the_references); everything else belongs to the first
+    // and of the packet path walk instead when it fits the LDS (kernels.hip: hit_is_the_references); everything else
+    // belongs to the first
     struct FastTree {
-        DevBuf<float4> nodes, triA, triB, leaf_box;
+        DevBuf<float4> nodes, triA, triB, triM, leaf_box;
         DevBuf<float2> triC;
+        DevBuf<float4> eye_nodes, eye_tri;      // its eye-relative copy for the packet path (device_scene.h: FrameDev::eye_nodes2)
+        uint32_t eye_key[4] = {0, 0, 0, 0};
         int n_slots = 0, coords_ok = 0, stack_entries = 0;
         bool ok = false;
     } fast;
@@ -332,10 +335,13 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
         c->last_two_trees = false;
         return MRT_OK;
     }
-    // a scene with a second tree (mrt_scene_upload_lbvh_exact): the recursive shader walks that one, in the persistent kernel
-    const bool two_trees = c->fast.ok && mode == (int)MRT_MODE_RECURSIVE && c->scene.n_objects == 0 && env_int("MRT_TWO_TREES", 1) != 0;
+    // a scene with a second tree (mrt_scene_upload_lbvh_exact): the recursive shader walks that one in the persistent kernel,
+    // the packet path in the one-wave-per-tile kernel
+    const bool second_tree = c->fast.ok && c->scene.n_objects == 0 && env_int("MRT_TWO_TREES", 1) != 0;
+    const bool two_trees = second_tree && mode == (int)MRT_MODE_RECURSIVE;
     bool resident = two_trees || (c->resident && mode == (int)MRT_MODE_RECURSIVE && c->scene.n_objects == 0);
     if (env_int("MRT_RESIDENT_PACKET", 0)) resident = c->resident && c->scene.n_objects == 0;
+    const bool two_trees_packet = second_tree && mode == (int)MRT_MODE_PACKET && !resident;
     if (resident && F.n_tiles < (1 << 24) && !(flags & MRT_FLAG_FRAME_ORDER)) {
         // Launches of the same shape follow each other in a frame loop with a slowly moving camera:
         // start the tiles that were expensive last time first.
@@ -400,16 +406,28 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
         F.eye_nodes = c->d_eye_nodes.p; F.eye_tri = c->d_eye_tri.p; F.eye_g = c->d_eye_g.p;
     }
     SceneDev S = c->scene;
-    if (two_trees) {
-        SceneDev fast = c->scene;
+    SceneDev fast = c->scene;
+    if (two_trees || two_trees_packet) {
         fast.nodes = c->fast.nodes.p; fast.triA = c->fast.triA.p; fast.triB = c->fast.triB.p; fast.triC = c->fast.triC.p;
-        fast.triG = nullptr; fast.triM = nullptr; fast.place = nullptr; fast.leaf_box = c->fast.leaf_box.p;
+        fast.triG = nullptr; fast.triM = c->fast.triM.p; fast.place = nullptr; fast.leaf_box = c->fast.leaf_box.p;
         fast.n_node_slots = c->fast.n_slots; fast.coords_ok = c->fast.coords_ok;
-        fast.ref_nodes = S.nodes; fast.ref_triA = S.triA; fast.ref_triB = S.triB; fast.ref_triC = S.triC; fast.ref_place = S.place;
-        fast.ref_coords_ok = S.coords_ok;
+        fast.ref_nodes = S.nodes; fast.ref_triA = S.triA; fast.ref_triB = S.triB; fast.ref_triC = S.triC; fast.ref_triM = S.triM; fast.ref_triG = S.triG;
+        fast.ref_place = S.place; fast.ref_coords_ok = S.coords_ok;
+    }
+    if (two_trees_packet) {
+        uint32_t key[4];
+        memcpy(key, F.cam, 12);
+        key[3] = c->scene_serial;
+        if (memcmp(key, c->fast.eye_key, sizeof key) != 0) {
+            MRT_HIP(c, launch_eye_relative(fast, F.cam, c->group_pad, c->fast.eye_nodes.p, c->fast.eye_tri.p, c->d_eye_g.p, stream));
+            memcpy(c->fast.eye_key, key, sizeof key);
+        }
+        F.eye_nodes2 = c->fast.eye_nodes.p; F.eye_tri2 = c->fast.eye_tri.p;
+    }
+    if (two_trees || two_trees_packet) {
         FrameDev Ff = F;
-        Ff.stack_entries = c->fast.stack_entries;        // (enough for either tree: mrt_scene_upload_lbvh_exact)
-        MRT_HIP(c, launch_render_second_tree(fast, Ff, c->n_cus, env_int("MRT_RESIDENT_THREADS", kResidentThreads), stream));
+        if (two_trees) Ff.stack_entries = c->fast.stack_entries;        // (enough for either tree: mrt_scene_upload_lbvh_exact)
+        MRT_HIP(c, launch_render_second_tree(fast, Ff, mode, c->n_cus, env_int("MRT_RESIDENT_THREADS", kResidentThreads), stream));
     } else {
     if (mode == (int)MRT_MODE_RECURSIVE && S.triG) {
         // the recursive shader's primary rays read the scene's own group boxes: this frame's copy of them stands
@@ -432,7 +450,7 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
     c->last_n_lights = c->scene.n_lights;
     c->last_n_tiles = F.n_tiles;
     c->last_ordered = F.tile_order != nullptr;
-    c->last_two_trees = two_trees;
+    c->last_two_trees = two_trees || two_trees_packet;
     return MRT_OK;
 }
 
@@ -500,7 +518,8 @@ void mrt_destroy(mrt_ctx* c) {
     c->d_fb.release(); c->d_ids.release(); c->d_counters.release();
     c->d_tile_cost.release(); c->d_tile_packed.release(); c->d_tile_order.release(); c->d_tile_state.release();
     c->d_tile_spread_a.release(); c->d_tile_spread_b.release();
-    c->fast.nodes.release(); c->fast.triA.release(); c->fast.triB.release(); c->fast.triC.release(); c->fast.leaf_box.release();
+    c->fast.nodes.release(); c->fast.triA.release(); c->fast.triB.release(); c->fast.triC.release(); c->fast.triM.release(); c->fast.leaf_box.release();
+    c->fast.eye_nodes.release(); c->fast.eye_tri.release();
     raster_release(c->raster);
     refit_release(c->refit);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -687,7 +706,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
     if (!flatten_meshes(meshes, n_meshes, n_textures, true, c->bvh.tris, err)) return fail(c, MRT_E_ARG, err);
     stage("flatten");
     if (lbvh && !c->bvh.tris.empty()) {
-        if (!build_lbvh_device(c->bvh, c->stream, err)) return fail(c, MRT_E_HIP, err);
+        if (!build_lbvh_device(c->bvh, c->stream, err, (float)env_int("MRT_LBVH_COST", 0) * 0.1f)) return fail(c, MRT_E_HIP, err);
     } else {
         build_bvh(c->bvh);
     }
@@ -880,7 +899,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
             // root's (the gate every ray passes first: the same box, the same arithmetic in both trees) stands back by
             // 2^-16 of the scene's largest coordinate.
             const float pad = largest * 0x1p-16f;
-            std::vector<float4> fnodes(2 * fslots), fA(T.n_tris), fB(T.n_tris), fbox(2 * (size_t)T.n_tris);
+            std::vector<float4> fnodes(2 * fslots), fA(T.n_tris), fB(T.n_tris), fM(3 * (size_t)T.n_tris), fbox(2 * (size_t)T.n_tris);
             std::vector<float2> fC(T.n_tris);
             bool fcoords = true;
             for (size_t i = 0; i < fslots; ++i) {
@@ -898,6 +917,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
                 fA[k] = make_float4(e1.x, e1.y, e1.z, e2.x);
                 fB[k] = make_float4(e2.y, e2.z, t.p0.x, t.p0.y);
                 fC[k] = make_float2(t.p0.z, bits2f(id));
+                fM[3 * k] = fA[k]; fM[3 * k + 1] = fB[k]; fM[3 * k + 2] = make_float4(t.p0.z, bits2f(id), 0.0f, 0.0f);
             }
             for (uint32_t i = 0; i <= B.pool_ptr; ++i) {
                 if (i == 1 || i == 2) continue;
@@ -910,6 +930,10 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
             MRT_HIP(c, c->fast.triA.upload(fA, c->stream));
             MRT_HIP(c, c->fast.triB.upload(fB, c->stream));
             MRT_HIP(c, c->fast.triC.upload(fC, c->stream));
+            MRT_HIP(c, c->fast.triM.upload(fM, c->stream));
+            MRT_HIP(c, c->fast.eye_nodes.ensure(2 * fslots));
+            MRT_HIP(c, c->fast.eye_tri.ensure(4 * (size_t)T.n_tris));
+            memset(c->fast.eye_key, 0, sizeof c->fast.eye_key);
             MRT_HIP(c, c->fast.leaf_box.upload(fbox, c->stream));
             MRT_HIP(c, hipStreamSynchronize(c->stream));
             c->fast.n_slots = (int)fslots;

@@ -1,4 +1,5 @@
-"""mrt_scene_upload_lbvh_exact: the recursive shader walks a second, GPU-built tree held in LDS, and every result must
+"""mrt_scene_upload_lbvh_exact: the recursive shader (second tree in LDS) and the packet path (both trees in global
+memory) walk a second, GPU-built tree, and every result must
 still be the reference's -- hit IDs, pixels and ray counts are held to those of the SAME library on the reference's own
 tree (bit for bit: the arithmetic per ray is the same, only the tree differs) and to the CPU oracle (the usual bar).
 mrt_get_second_tree_use shows that the second tree was really walked, and how many rays had to ask the first.
@@ -39,7 +40,7 @@ def _same(a, b, what=""):
 def test_frames_through_the_second_tree_equal_those_through_the_first(maze_scene, maze_oracle, W, H):
     one, two = _pair(maze_scene, W, H)
     n_tiles = (W // 8) * (H // 8)
-    retraced = split = 0
+    retraced = retraced_packets = split = 0
     for pose in list(POSES[:5]) + EXTRA:
         cam = pose_cam(pose)
         want = _frame(one, cam, MODE_RECURSIVE)
@@ -55,24 +56,29 @@ def test_frames_through_the_second_tree_equal_those_through_the_first(maze_scene
         if (W, H) == (256, 144):
             ref = maze_oracle.render(cam, W, H, mode=MODE_RECURSIVE)
             assert np.array_equal(got[1], ref["ids"]) and colour_mismatch_fraction(got[0], ref["fb"]) <= 0.001
-        # a sample grid (never split) and a band of rows
+        # the packet path
+        _same(_frame(two, cam, MODE_PACKET), _frame(one, cam, MODE_PACKET), pose[0] + " packet path")
+        walked, again = two.second_tree_use()
+        assert walked
+        retraced_packets += again
+        # a sample grid (never split)
         if (W, H) != (1920, 1080):
             _same(_frame(two, cam, MODE_RECURSIVE, spp_grid=2), _frame(one, cam, MODE_RECURSIVE, spp_grid=2), pose[0] + " grid 2")
+            _same(_frame(two, cam, MODE_PACKET, spp_grid=4), _frame(one, cam, MODE_PACKET, spp_grid=4), pose[0] + " packet path, grid 4")
     if (W, H) == (1920, 1080):
-        assert retraced > 0, "no ray of these views had to ask the reference's tree: the poses no longer cover that path"
+        assert retraced > 0 and retraced_packets > 0, "no ray of these views had to ask the reference's tree: the poses no longer cover that path"
     if (W, H) == (800, 600):
         assert split > 0, "no tile was handed out in sixteenths"
     one.close(); two.close()
 
 
-def test_everything_but_the_recursive_shader_goes_through_the_first_tree(maze_scene):
+def test_what_goes_through_the_first_tree(maze_scene):
     W, H = 320, 200
     one, two = _pair(maze_scene, W, H)
     cam = pose_cam(POSES[1])
-    for mode in (MODE_PACKET, MODE_BVH_DEPTH):
-        got, want = two.render(cam, mode=mode), one.render(cam, mode=mode)
-        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
-        assert two.second_tree_use() == (False, 0)
+    got, want = two.render(cam, mode=MODE_BVH_DEPTH), one.render(cam, mode=MODE_BVH_DEPTH)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert two.second_tree_use() == (False, 0)
     # the traversal operators
     rng = np.random.default_rng(3)
     O = rng.uniform([-15, 0, -15], [15, 4, 15], (4096, 3)).astype(np.float32)
@@ -84,8 +90,9 @@ def test_everything_but_the_recursive_shader_goes_through_the_first_tree(maze_sc
     # analytic primitives are not in the second tree: such frames go through the first
     spheres = np.float32([[0, 1, 1.5, 0, 0.5, 1, 0, 1, 0, 0.5, 0.0, 1.0, 0], [0, -1, 1.5, 0, 0.5, 1, 1, 1, 1, 0.0, 0.5, 1.5, 0]])
     one.set_objects(spheres); two.set_objects(spheres)
-    _same(_frame(two, cam, MODE_RECURSIVE), _frame(one, cam, MODE_RECURSIVE), "with spheres")
-    assert two.second_tree_use() == (False, 0)
+    for mode in (MODE_RECURSIVE, MODE_PACKET):
+        _same(_frame(two, cam, mode), _frame(one, cam, mode), "with spheres")
+        assert two.second_tree_use() == (False, 0)
     one.set_objects(np.zeros((0, 12), np.float32)); two.set_objects(np.zeros((0, 12), np.float32))
     _same(_frame(two, cam, MODE_RECURSIVE), _frame(one, cam, MODE_RECURSIVE), "spheres removed")
     assert two.second_tree_use()[0]
@@ -107,11 +114,13 @@ def test_lights_materials_and_refit(maze_scene):
         pos = np.asarray(m["pos"], np.float32) + np.float32([0.0, 0.25, 0.0])
         moved["meshes"].append(dict(m, pos=pos, bounds=np.concatenate([pos.min(0), pos.max(0)]).astype(np.float32)))
     one.refit(moved); two.refit(moved)
-    _same(_frame(two, cam, MODE_RECURSIVE), _frame(one, cam, MODE_RECURSIVE), "after the refit")
-    assert two.second_tree_use() == (False, 0)
+    for mode in (MODE_RECURSIVE, MODE_PACKET):
+        _same(_frame(two, cam, mode), _frame(one, cam, mode), "after the refit")
+        assert two.second_tree_use() == (False, 0)
     two.build_bvh(moved, lbvh="exact"); one.build_bvh(moved)
-    _same(_frame(two, cam, MODE_RECURSIVE), _frame(one, cam, MODE_RECURSIVE), "uploaded again")
-    assert two.second_tree_use()[0]
+    for mode in (MODE_RECURSIVE, MODE_PACKET):
+        _same(_frame(two, cam, mode), _frame(one, cam, mode), "uploaded again")
+        assert two.second_tree_use()[0]
     one.close(); two.close()
 
 
@@ -147,13 +156,17 @@ def test_device_frames_shares_and_the_entry_point_without_allocations(maze_scene
             call(cam, fb.data_ptr(), W, mode=MODE_RECURSIVE, stream=stream)
             torch.cuda.synchronize()
             assert torch.equal(fb, want) and two.second_tree_use()[0] and two.ray_counts() == counts
-    # interleaved shares of the frame (the multi-GPU split), rendered one after the other into one frame
-    fb = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
-    for part in range(3):
-        two.render_device_part(cam, fb.data_ptr(), W, part, 3, block_tile_rows=2, mode=MODE_RECURSIVE, stream=stream)
-        assert two.second_tree_use()[0]
-    torch.cuda.synchronize()
-    assert torch.equal(fb, want)
+    # interleaved shares of the frame (the multi-GPU split), rendered one after the other into one frame: both shaders,
+    # the packet path with a sample grid as bench.py --gpus N renders it
+    for mode, grid in ((MODE_RECURSIVE, 1), (MODE_PACKET, 2)):
+        whole = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
+        one.render_device(cam, whole.data_ptr(), W, mode=mode, spp_grid=grid, stream=stream)
+        fb = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
+        for part in range(3):
+            two.render_device_part(cam, fb.data_ptr(), W, part, 3, block_tile_rows=2, mode=mode, spp_grid=grid, stream=stream)
+            assert two.second_tree_use()[0]
+        torch.cuda.synchronize()
+        assert torch.equal(fb, whole)
     # a band of rows
     fb = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
     two.render_device(cam, fb.data_ptr(), W, mode=MODE_RECURSIVE, rows=(64, 200), stream=stream)
