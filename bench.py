@@ -375,7 +375,9 @@ def main():
         golden = json.load(f)
     metric = "Mrays/sec (primary+secondary) and ms/frame at 1080p/8K, 1/2/4/8 MI355X"
     c4_workload = ("default maze scene (2120 triangles, 1 light), ONE 7680x4320 frame per step at 16 samples per pixel (4x4 grid: 30720x17280 "
-                   "traced), packet path + shadow rays, default camera; scene replicated, 8-row tile rows dealt round-robin to the ranks, "
+                   "traced), packet path + shadow rays, default camera, scene uploaded with mrt_scene_upload_lbvh_exact like the N = 1 "
+                   "headline's (the packets walk the second tree; results identical to mrt_scene_upload's); scene replicated, 8-row tile rows "
+                   "dealt round-robin to the ranks, "
                    "shares gathered on rank 0 (RCCL send/recv, queued by libmrt_gather.so; --exchange torch: by torch.distributed)")
 
     def c4_roofline(r4):
@@ -385,7 +387,7 @@ def main():
         t4 = traffic_of("c4")
         if t4["traffic"] is not None:
             t4["traffic"] = int(t4["traffic"] / world)
-        return valu_roofline(flops_of(g4) / world, r4["kernel_ms"], "render_tiles_global<packet>",
+        return valu_roofline(flops_of(g4) / world, r4["kernel_ms"], "render_tiles_two_trees_packet",
                              counts="tests/golden/full_size.json (oracle, offline)", share_of_frame=1.0 / world,
                              hbm={"algorithmic_bytes_per_launch": 4 * 7680 * 4320 // world, "peak_GBps": 8000}, **t4)
 
@@ -455,7 +457,7 @@ def main():
             b8 = ora["fb"].view(np.uint8).reshape(-1, 4).astype(np.int16)
             out["parity"].update({"pixels_beyond_1_255": float((np.abs(a8 - b8).max(axis=1) > 1).mean()), "pixels_different": int((a8 != b8).any(axis=1).sum())})
     else:
-        head = Workload("c4", scene, 7680, 4320, MODE_PACKET, 4, cam, rank, world, torch, dist, split="rows", exchange=args.exchange)
+        head = Workload("c4", scene, 7680, 4320, MODE_PACKET, 4, cam, rank, world, torch, dist, split="rows", exchange=args.exchange, tree="exact")
         res = head.run(args.steps, args.warmup)
         got = head.frame() if rank == 0 else None
         if rank == 0:
@@ -592,14 +594,18 @@ def main():
                                  "frame_hash_equals_oracle": _fbsum(wl.frame()) == golden["c2_maze_1080p_recursive"]["fbsum"]}
         del wl, rt_gpu
     if not args.no_extra and world == 1:
-        c4 = Workload("c4", scene, 7680, 4320, MODE_PACKET, 4, cam, rank, world, torch, dist, split="rows")
+        c4 = Workload("c4", scene, 7680, 4320, MODE_PACKET, 4, cam, rank, world, torch, dist, split="rows", tree="exact")
         r4 = c4.run(max(2, min(args.steps, 5)), 1)
+        assert c4.rt.second_tree_use()[0]
         out["c4_8k_16spp"] = {"workload": c4_workload, "scaling": "strong", "value": round(r4["mrays_per_s"], 3), "unit": "Mrays/s",
                               "ms_per_frame": round(r4["ms_per_step"], 4), "kernel_ms": round(r4["kernel_ms"], 4),
                               "rays_per_frame": r4["rays_per_step"], "roofline": c4_roofline(r4),
                               "frame_hash_equals_oracle": _fbsum(c4.frame()) == golden["c4_maze_8k_16spp_packet"]["fbsum"]}
         assert out["c4_8k_16spp"]["frame_hash_equals_oracle"]
         del c4
+        c4r = Workload("c4ref", scene, 7680, 4320, MODE_PACKET, 4, cam, rank, world, torch, dist, split="rows", tree=False)
+        out["c4_8k_16spp"]["reference_tree_only_ms_per_frame"] = round(c4r.run(2, 1)["ms_per_step"], 4)
+        del c4r
     if not args.no_extra and world > 1:
         # N whole 1080p recursive frames per step, one per rank, gathered on rank 0 (what a frame loop does with frames too small to cut)
         fr = Workload("c2", scene, W, H, MODE_RECURSIVE, 1, cam, rank, world, torch, dist, split="frames", exchange=args.exchange, tree="exact")
@@ -624,14 +630,21 @@ def main():
             assert ok
         del fr
     if not args.no_extra and world == 1:
-        pk = Workload("packet1080p", scene, W, H, MODE_PACKET, 1, cam, rank, world, torch, dist)
+        pk = Workload("packet1080p", scene, W, H, MODE_PACKET, 1, cam, rank, world, torch, dist, tree="exact")
         rp = pk.run(args.steps, args.warmup)
+        assert pk.rt.second_tree_use()[0]
+        pkr = Workload("packet1080pref", scene, W, H, MODE_PACKET, 1, cam, rank, world, torch, dist, tree=False)
+        rpr = pkr.run(args.steps, args.warmup)
+        assert np.array_equal(pkr.frame(), pk.frame())
+        del pkr
         gp = golden["c2_maze_1080p_packet"]
         assert _fbsum(pk.frame()) == gp["fbsum"] and gp["counters"]["primary_rays"] + gp["counters"]["shadow_rays"] == rp["rays_per_step"]
-        out["packet_path"] = {"workload": "same scene, 1920x1080, 64-ray packets + shadow rays (Raytracer::Render)",
+        out["packet_path"] = {"workload": "same scene (uploaded like the headline's: the packets walk the second tree), 1920x1080, 64-ray packets + "
+                                          "shadow rays (Raytracer::Render); `reference_tree_only_ms_per_step`: through mrt_scene_upload, identical frame",
+                              "reference_tree_only_ms_per_step": round(rpr["ms_per_step"], 5),
                               "value": round(rp["mrays_per_s"], 3), "unit": "Mrays/s", "ms_per_step": round(rp["ms_per_step"], 5),
                               "kernel_ms": round(rp["kernel_ms"], 5), "rays_per_frame": rp["rays_per_step"],
-                              "roofline": valu_roofline(flops_of(gp["counters"]), rp["kernel_ms"], "render_tiles_global<packet>", **traffic_of("c2p"))}
+                              "roofline": valu_roofline(flops_of(gp["counters"]), rp["kernel_ms"], "render_tiles_two_trees_packet", **traffic_of("c2p"))}
         if not args.no_cpu:
             op = oracle_work_and_baseline(scene, W, H, MODE_PACKET, cam, threads, max(3.0, args.cpu_seconds / 3))
             out["packet_path"]["cpu_value"] = round(op["rays"] / op["best_s"] / 1e6, 3)
@@ -639,7 +652,7 @@ def main():
             out["packet_path"]["cpu_cores"] = threads
             out["packet_path"]["speedup_over_cpu"] = round(rp["mrays_per_s"] / out["packet_path"]["cpu_value"], 1)
         del pk
-        c1 = Workload("c1", scene, 512, 512, MODE_PACKET, 1, cam, rank, world, torch, dist)
+        c1 = Workload("c1", scene, 512, 512, MODE_PACKET, 1, cam, rank, world, torch, dist, tree="exact")
         r1 = c1.run(args.steps, args.warmup)
         out["c1_512_packet"] = {"workload": "same scene, 512x512, 64-ray packets + shadow rays: the reference's own CPU-runnable configuration",
                                 "value": round(r1["mrays_per_s"], 3), "unit": "Mrays/s", "ms_per_step": round(r1["ms_per_step"], 5),
@@ -649,7 +662,7 @@ def main():
             out["c1_512_packet"]["cpu_value"] = round(o1["rays"] / o1["best_s"] / 1e6, 3)
             out["c1_512_packet"]["cpu_ms_per_frame"] = round(o1["best_s"] * 1e3, 3)
             out["c1_512_packet"]["cpu_cores"] = threads
-            out["c1_512_packet"]["roofline"] = valu_roofline(o1["flops"], r1["kernel_ms"], "render_tiles_global<packet>")
+            out["c1_512_packet"]["roofline"] = valu_roofline(o1["flops"], r1["kernel_ms"], "render_tiles_two_trees_packet")
             assert o1["rays"] == r1["rays_per_step"] and np.array_equal(c1.frame(), o1["fb"])
         del c1
         soup = scene_io.large_scene(scene)

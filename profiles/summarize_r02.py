@@ -15,7 +15,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOMINANT = {"c2": "render_tiles_resident<1, true>", "c2r": "render_tiles_resident<1, false>", "c2p": "render_tiles_global<0, 16>", "c4": "render_tiles_global<0, 16>",
+DOMINANT = {"c2": "render_tiles_resident<1, true>", "c2r": "render_tiles_resident<1, false>", "c2p": "render_tiles_two_trees_packet<true>", "c4": "render_tiles_two_trees_packet<true>",
             "c3": "render_tiles_global<0, 32>", "c5": "raster_tile<4>"}
 
 

@@ -28,7 +28,7 @@ def main():
     if scene is None:
         scene = scene_io.large_scene(maze)
     rt = Raytracer(W, H, device=0)
-    rt.build_bvh(scene, lbvh="exact" if cfg == "c2" else False)
+    rt.build_bvh(scene, lbvh="exact" if cfg in ("c2", "c2p", "c4") else False)       # (as bench.py uploads them)
     cam = np.eye(4, dtype=np.float32).reshape(16)
     fb = torch.zeros((H, W), dtype=torch.int32, device="cuda")
     st = torch.cuda.current_stream()
