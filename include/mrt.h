@@ -100,14 +100,15 @@ int mrt_scene_upload_lbvh(mrt_ctx* ctx, const mrt_mesh* meshes, int n_meshes,
 
 /* Raytracer::BuildBVH(meshList) (game.cpp:34; raytracer.cpp:670-673) with two trees: everything mrt_scene_upload
  * does -- the reference's own tree (raytracer.cpp:897-1203) serves every call as it does there --, and beside it the
- * GPU-built tree of mrt_scene_upload_lbvh over the same triangles.  Frames of the recursive shader
- * (MRT_MODE_RECURSIVE, a scene that fits the LDS, no analytic primitives) walk the second tree, which is the faster
- * one, and report what BVH::Traverse (raytracer.cpp:1204-1264, 1328-1346) reports on the reference's tree: a ray's
- * result is taken from the second tree only where it can be shown to be the reference's (no other triangle as near
- * to within rounding, and the ray passes the hit triangle's leaf box of the reference's tree by the reference's
- * arithmetic); the few tiles with a ray for which that cannot be shown are rendered again through the reference's tree
- * within the same call.  Hit IDs, pixels and ray counts are those of mrt_scene_upload; only the time differs.  The
- * upload costs both builds.  After mrt_scene_refit the second tree is no longer used. */
+ * GPU-built tree of mrt_scene_upload_lbvh over the same triangles.  Frames of the recursive shader and of the packet
+ * path (MRT_MODE_RECURSIVE, MRT_MODE_PACKET; a scene that fits the LDS, no analytic primitives) walk the second tree,
+ * which is the faster one, and report what BVH::Traverse and BVH::TraverseRayPacket (raytracer.cpp:1204-1264,
+ * 1328-1464) report on the reference's tree: a ray's result is taken from the second tree only where it can be shown to
+ * be the reference's (no other triangle as near to within rounding, and the ray passes the hit triangle's leaf box of
+ * the reference's tree by the reference's arithmetic); a ray for which that cannot be shown -- on the packet path its
+ * whole packet -- is traced again through the reference's tree within the same kernel.  Hit IDs, pixels and ray counts
+ * are those of mrt_scene_upload; only the time differs.  The upload costs both builds.  After mrt_scene_refit the
+ * second tree is no longer used. */
 int mrt_scene_upload_lbvh_exact(mrt_ctx* ctx, const mrt_mesh* meshes, int n_meshes,
                                 const mrt_texture* textures, int n_textures);
 
@@ -278,9 +279,9 @@ int mrt_get_ray_counts(mrt_ctx* ctx, uint64_t out[4]);
 int mrt_get_tile_schedule(mrt_ctx* ctx, uint64_t out[2]);
 
 /* Scenes uploaded with mrt_scene_upload_lbvh_exact (no counterpart in the reference, which has one tree): out[0] = 1 if
- * the most recent render walked the scene's second tree, else 0; out[1] = tiles of that render that were rendered again
- * through the reference's tree because a ray's result could not be shown to be the reference's from the second tree
- * alone.  Synchronises like mrt_get_ray_counts.  The pixels do not depend on any of this. */
+ * the most recent render walked the scene's second tree, else 0; out[1] = rays of that render (packet path: packets)
+ * that were traced again through the reference's tree because a result could not be shown to be the reference's from
+ * the second tree alone.  Synchronises like mrt_get_ray_counts.  The pixels do not depend on any of this. */
 int mrt_get_second_tree_use(mrt_ctx* ctx, uint64_t out[2]);
 
 /* Camera::LookAt (scenedata.h:129-134): out = inverse(lookAt(pos, target, (0,1,0))) with the
