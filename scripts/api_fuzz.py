@@ -3,7 +3,9 @@
 shares, queued frames, rasterizer frames (host and device), light changes, refits with moved vertices, object lists,
 the BVH-depth view, the entry point that allocates nothing, context destruction) with every frame checked against a
 frame rendered by a fresh context for the same scene, lights and camera.  Looks for state that leaks from one call
-into the next (tile order, cost history, pair buffer, queued-frame slots).  usage: api_fuzz.py [ops] [seed]"""
+into the next (tile order, cost history, pair buffer, queued-frame slots).  Half of the uploads of the contexts under
+test are mrt_scene_upload_lbvh_exact (two trees); the fresh contexts always hold the reference's tree alone.
+usage: api_fuzz.py [ops] [seed]"""
 import os
 import sys
 
@@ -51,9 +53,11 @@ def main():
             o[i, 9:12] = [rng.choice([0, 0.4]), rng.choice([0, 0.3]), rng.choice([1.0, 1.5])]
         return o
 
-    def fresh(scene_name, lights, variant=0, objects=no_objects):
+    def fresh(scene_name, lights, variant=0, objects=no_objects, two_trees=False):
+        # two_trees: uploaded with mrt_scene_upload_lbvh_exact (contexts under test, half of the time); the contexts that
+        # make the reference frames always hold the reference's tree alone
         rt = Raytracer(W, H, device=0)
-        rt.build_bvh(scenes[scene_name])
+        rt.build_bvh(scenes[scene_name], lbvh="exact" if two_trees else False)
         if variant:
             rt.refit(moved(scene_name, variant))       # the same tree as the context under test: refit keeps the uploaded one
         rt.set_lights(lights)
@@ -93,7 +97,7 @@ def main():
         if not ctx or (len(ctx) < 3 and rng.random() < 0.15):
             name = str(rng.choice(list(scenes)))
             lights = rand_lights()
-            ctx.append([fresh(name, lights), name, lights, 0, no_objects])
+            ctx.append([fresh(name, lights, two_trees=rng.random() < 0.5), name, lights, 0, no_objects])
             continue
         k = int(rng.integers(0, len(ctx)))
         rt, name, lights, variant, objects = ctx[k]
@@ -106,7 +110,7 @@ def main():
             ctx.pop(k)
         elif what < 0.12:
             name = str(rng.choice(list(scenes)))
-            rt.build_bvh(scenes[name])
+            rt.build_bvh(scenes[name], lbvh="exact" if rng.random() < 0.5 else False)
             ctx[k][1], ctx[k][3] = name, 0            # a new upload; lights and objects stay with the context
         elif what < 0.18:
             lights = rand_lights()
