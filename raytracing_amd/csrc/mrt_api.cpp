@@ -873,7 +873,9 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
                   resident_lds_bytes((int)slots, (int)B.n_tris, c->stack_entries, true) + 256 <= (size_t)kLdsBudget;
     c->resident = c->resident && env_int("MRT_RESIDENT", 1) != 0;      // 0 forces the global-memory kernel
     c->fast.ok = false;
-    if (source == TreeSource::LbvhExact && B.n_tris > 0) {
+    // (a reference tree that is one leaf has nothing to gain, and its leaf is entered through the root gate's own
+    // arithmetic, raytracer.cpp:947, not through a parent's box test, which is what the second tree's rays are checked by)
+    if (source == TreeSource::LbvhExact && B.n_tris > 0 && B.count[0] == 0) {
         // the second tree: built on the GPU over the same triangles, kept only if the persistent kernel can hold it in LDS
         // (with ever larger leaves until its nodes, the triangles and the waves' stacks fit)
         HostBVH T;
