@@ -18,7 +18,7 @@ def main():
     w, h = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1920, 1080)
     scene = scene_io.load_scene(os.path.join(ROOT, "tests", "golden", "maze.mrts"))
     rt = Raytracer(w, h, device=0)
-    rt.build_bvh(scene)
+    rt.build_bvh(scene, lbvh="exact" if os.environ.get("MRT_PROBE_TREE", "exact") == "exact" else False)     # (as bench.py uploads it)
     fb = torch.zeros((h, w), dtype=torch.int32, device="cuda")
     st = torch.cuda.current_stream()
     xs = [0.16 * k for k in list(range(1, 26)) + list(range(24, -1, -1))]
