@@ -68,6 +68,7 @@ struct SceneDev {
     // mrt_scene_upload_lbvh_exact (kernels.hip: hit_is_the_references): per triangle ID the box of its leaf in the
     // REFERENCE's tree, {min.xyz, 0}, {max.xyz, 0}; and the reference's tree itself, for the rays that have to ask it.
     const float4* leaf_box;
+    float reach;          // 64 times the scene's largest coordinate: ray origins within it may use the second tree's cheap box test (kernels.hip: slab_mul_pair)
     const float4* ref_nodes;
     const float4* ref_triA;
     const float4* ref_triB;

@@ -112,7 +112,8 @@ struct SceneGlobalT {
     const v4u* triG;      // group boxes (device_scene.h)
     const v4f* triM;      // the same triangles as one 48-byte record each (device_scene.h): one address per test
     const uint2* place;   // triangle id -> {place in the tree's own leaf order, first place of its leaf} (device_scene.h)
-    const v4f* leaf_box = nullptr;      // (only the LDS-resident kernel walks a tree that needs them: SceneDev::leaf_box)
+    const v4f* leaf_box = nullptr;      // (SceneDev::leaf_box: set when these arrays are a scene's second tree)
+    float reach = 0.0f;                 // (SceneDev::reach, with leaf_box)
     static constexpr bool kMergedTris = true;
     __device__ __forceinline__ bool has_groups() const { return G; }
     __device__ __forceinline__ v4u group(uint32_t g) const { return triG[g]; }
@@ -159,6 +160,7 @@ struct SceneLds {
     MRT_LDS const v4u* triG; bool groups;
     const uint2* place;   // (global memory: read only when two hits are equally far)
     const v4f* leaf_box;  // (global memory: SceneDev::leaf_box, or null)
+    float reach;          // (SceneDev::reach, with leaf_box)
     SceneGlobalT<false> ref;      // with leaf_box: the reference's own tree, in global memory (SceneDev::ref_nodes ...)
     static constexpr bool kMergedTris = false;
     __device__ __forceinline__ bool has_groups() const { return groups; }
@@ -248,15 +250,17 @@ __device__ __forceinline__ void slab_div_pair(v4f l0, v4f l1, v4f r0, v4f r1, co
 
 // Both children of an inner node of a scene's SECOND tree (hit_is_the_references): its boxes stand back from their
 // triangles by 2^-16 of the scene's largest coordinate and need not reproduce the reference's arithmetic -- only never
-// dismiss a box that holds a hit -- so the quotients are plain products with the reciprocal direction (2^-23 of the
-// quotient off at most, a hundredth of what the boxes stand back by while the eye is within a hundred scene sizes,
-// which the ranges of the exact-division shortcut guarantee: `shortcut` must hold for the calling lanes).  24 operations
+// dismiss a box that holds a hit -- so a quotient (b - O) / D is one fused multiply-add, b * r - ro with r = 1 / D and
+// ro = O * r: off by 2^-24 (|O| |r| + |quotient|) at most, while the boxes stand back by 2^-16 of the scene's largest
+// coordinate, times |r| in the quotient -- sixty times the error for an origin within SceneDev::reach (64 scene sizes).
+// The caller sees to that and to r being an ordinary number (ranges of the exact-division shortcut).  12 operations
 // for the twelve quotients instead of 84.
-__device__ __forceinline__ void slab_mul_pair(v4f l0, v4f l1, v4f r0, v4f r1, const RayDiv& R, float t,
+__device__ __forceinline__ void slab_mul_pair(v4f l0, v4f l1, v4f r0, v4f r1, const RayDiv& R, f3 ro, float t,
                                               bool& leftN, bool& rightN, float& tNear, float& tNear2) {
     float tFar, tFar2;
-    slab_terms_finite((xyz(l0) - R.O) * R.r, (xyz(l1) - R.O) * R.r, tNear, tFar);
-    slab_terms_finite((xyz(r0) - R.O) * R.r, (xyz(r1) - R.O) * R.r, tNear2, tFar2);
+    auto q = [&](v4f b) { return f3{__builtin_fmaf(b.x, R.r.x, -ro.x), __builtin_fmaf(b.y, R.r.y, -ro.y), __builtin_fmaf(b.z, R.r.z, -ro.z)}; };
+    slab_terms_finite(q(l0), q(l1), tNear, tFar);
+    slab_terms_finite(q(r0), q(r1), tNear2, tFar2);
     leftN = slab_pass(tNear, tFar, t);
     rightN = slab_pass(tNear2, tFar2, t);
 }
@@ -682,7 +686,8 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
     }
     MRT_TICK(wd, 2);
     const RayDiv R = make_ray_div(O, D, coords_ok);
-    const bool shortcut = __all(R.shortcut);
+    const f3 ro = R.O * R.r;      // (EXACT: slab_mul_pair)
+    const bool shortcut = __all(R.shortcut && (!EXACT || (fabsf(O.x) <= sc.reach && fabsf(O.y) <= sc.reach && fabsf(O.z) <= sc.reach)));
     // groups of a long leaf may be skipped for rays whose reciprocal direction is an ordinary number on every axis
     const bool may_skip = sc.has_groups() && skip_ok && fabsf(R.r.x) < INFINITY && fabsf(R.r.y) < INFINITY && fabsf(R.r.z) < INFINITY;
     int sp = 0;
@@ -697,7 +702,7 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
             const v4f l0 = pair[0], l1 = pair[1], r0 = pair[2], r1 = pair[3];
             bool leftN, rightN;
             float tNear, tNear2;
-            if (EXACT && shortcut) slab_mul_pair(l0, l1, r0, r1, R, t * kExactCull, leftN, rightN, tNear, tNear2);
+            if (EXACT && shortcut) slab_mul_pair(l0, l1, r0, r1, R, ro, t * kExactCull, leftN, rightN, tNear, tNear2);
             else slab_div_pair(l0, l1, r0, r1, R, shortcut, EXACT ? t * kExactCull : t, leftN, rightN, tNear, tNear2);
             // raytracer.cpp:1239-1262 as selects: go right when only the right child passes, or when
             // both pass and the right one is entered first (tNear2 < tNear); the other passing
@@ -813,7 +818,8 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
     unsigned long long m = __ballot(gate);
     if (m == 0) return false;
     const RayDiv R = make_ray_div(O, D, coords_ok);
-    const bool shortcut = !__any(take_part && !R.shortcut);
+    const f3 ro = R.O * R.r;      // (EXACT: slab_mul_pair)
+    const bool shortcut = !__any(take_part && !(R.shortcut && (!EXACT || (fabsf(O.x) <= sc.reach && fabsf(O.y) <= sc.reach && fabsf(O.z) <= sc.reach))));
     const bool r_ok = skip_ok && fabsf(R.r.x) < INFINITY && fabsf(R.r.y) < INFINITY && fabsf(R.r.z) < INFINITY;
     float t = INFINITY;
     Hit h;
@@ -885,7 +891,7 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
             bool leftN, rightN;
             float nl = 0.0f, nr = 0.0f;          // entry distances (estimates will do: they only order the two children)
             if (EXACT && shortcut) {
-                slab_mul_pair(l0, l1, r0, r1, R, INFINITY, leftN, rightN, nl, nr);
+                slab_mul_pair(l0, l1, r0, r1, R, ro, INFINITY, leftN, rightN, nl, nr);
             } else {
                 const bool sure = shortcut && slab_pair_shadow_interval(l0, l1, r0, r1, R, leftN, rightN, nl, nr);
                 if (__any(((m >> lane) & 1ull) && !sure)) {
@@ -1443,7 +1449,7 @@ __global__ __launch_bounds__(64, MRT_PACKET_WAVES) void render_tiles_two_trees_p
     SceneTwoTreesT<GR> sc;
     sc.nodes = reinterpret_cast<const v4f*>(S.nodes); sc.triA = reinterpret_cast<const v4f*>(S.triA); sc.triB = reinterpret_cast<const v4f*>(S.triB);
     sc.triC = reinterpret_cast<const v2f*>(S.triC); sc.triG = nullptr; sc.triM = reinterpret_cast<const v4f*>(S.triM); sc.place = nullptr;
-    sc.leaf_box = reinterpret_cast<const v4f*>(S.leaf_box);
+    sc.leaf_box = reinterpret_cast<const v4f*>(S.leaf_box); sc.reach = S.reach;
     sc.eyeNodes = reinterpret_cast<const v4f*>(F.eye_nodes2); sc.eyeTri = reinterpret_cast<const v4f*>(F.eye_tri2); sc.eyeG = nullptr;
     sc.ref.nodes = reinterpret_cast<const v4f*>(S.ref_nodes); sc.ref.triA = reinterpret_cast<const v4f*>(S.ref_triA); sc.ref.triB = reinterpret_cast<const v4f*>(S.ref_triB);
     sc.ref.triC = reinterpret_cast<const v2f*>(S.ref_triC); sc.ref.triG = reinterpret_cast<const v4u*>(S.ref_triG); sc.ref.triM = reinterpret_cast<const v4f*>(S.ref_triM);
@@ -1600,7 +1606,7 @@ __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_t
         }
     }
     __syncthreads();
-    const SceneLds sc{l_nodes, l_a, l_b, l_c, l_g, S.triG != nullptr, S.place, reinterpret_cast<const v4f*>(S.leaf_box),
+    const SceneLds sc{l_nodes, l_a, l_b, l_c, l_g, S.triG != nullptr, S.place, reinterpret_cast<const v4f*>(S.leaf_box), S.reach,
                       SceneGlobalT<false>{reinterpret_cast<const v4f*>(S.ref_nodes), reinterpret_cast<const v4f*>(S.ref_triA), reinterpret_cast<const v4f*>(S.ref_triB),
                                           reinterpret_cast<const v2f*>(S.ref_triC), nullptr, nullptr, S.ref_place}};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

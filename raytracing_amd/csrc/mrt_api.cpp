@@ -139,6 +139,7 @@ struct mrt_ctx {
         DevBuf<float4> eye_nodes, eye_tri;      // its eye-relative copy for the packet path (device_scene.h: FrameDev::eye_nodes2)
         uint32_t eye_key[4] = {0, 0, 0, 0};
         int n_slots = 0, coords_ok = 0, stack_entries = 0;
+        float reach = 0.0f;
         bool ok = false;
     } fast;
     DevBuf<uint2> d_place;      // per triangle id: its place in the tree's own leaf order and its leaf's first place (device_scene.h: place)
@@ -410,7 +411,7 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
     if (two_trees || two_trees_packet) {
         fast.nodes = c->fast.nodes.p; fast.triA = c->fast.triA.p; fast.triB = c->fast.triB.p; fast.triC = c->fast.triC.p;
         fast.triG = nullptr; fast.triM = c->fast.triM.p; fast.place = nullptr; fast.leaf_box = c->fast.leaf_box.p;
-        fast.n_node_slots = c->fast.n_slots; fast.coords_ok = c->fast.coords_ok;
+        fast.n_node_slots = c->fast.n_slots; fast.coords_ok = c->fast.coords_ok; fast.reach = c->fast.reach;
         fast.ref_nodes = S.nodes; fast.ref_triA = S.triA; fast.ref_triB = S.triB; fast.ref_triC = S.triC; fast.ref_triM = S.triM; fast.ref_triG = S.triG;
         fast.ref_place = S.place; fast.ref_coords_ok = S.coords_ok;
     }
@@ -940,6 +941,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
             MRT_HIP(c, hipStreamSynchronize(c->stream));
             c->fast.n_slots = (int)fslots;
             c->fast.coords_ok = fcoords ? 1 : 0;
+            c->fast.reach = 64.0f * largest;
             c->fast.stack_entries = fstack;
             c->fast.ok = true;
             stage("second tree packed");

@@ -13,8 +13,10 @@ from raytracing_amd import MODE_BVH_DEPTH, MODE_PACKET, MODE_RECURSIVE, Raytrace
 pytestmark = pytest.mark.gpu
 
 # P1 looks at the maze from outside: a dozen of its rays pass two triangles within rounding of each other and are
-# traced again; the integer eye of "grid" sends rays along box faces
-EXTRA = [("grid", (14.0, 4.0, 19.0), (-7.4432807, 0.4908863, 3.5839818)), ("low", (6.863297, 2.8962514, -9.219043), (-11.901246, -0.24103431, -7.8104954))]
+# traced again; the integer eye of "grid" sends rays along box faces; "far" is beyond the distance up to which the second
+# tree's box tests take their shortcut (kernels.hip: slab_mul_pair)
+EXTRA = [("grid", (14.0, 4.0, 19.0), (-7.4432807, 0.4908863, 3.5839818)), ("low", (6.863297, 2.8962514, -9.219043), (-11.901246, -0.24103431, -7.8104954)),
+         ("far", (900.0, 700.0, 2500.0), (0.0, 0.0, 0.0))]
 
 
 def _pair(scene, W, H):
