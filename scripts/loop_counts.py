@@ -30,6 +30,7 @@ def main():
                     "soup:N (the large-scene generator) | mixed:N (that soup in three meshes: opaque, mirror, mirror + glass)")
     ap.add_argument("--pose", default="P0", help="P0 (identity) | P1 | soup (5,1,4) -> (0,0,-20) | inside (0,0.5,-23) -> (3,0,-30)")
     ap.add_argument("--gpu-tree", action="store_true", help="the tree mrt_scene_upload_lbvh builds on the GPU instead of the reference's")
+    ap.add_argument("--two-trees", action="store_true", help="the scene uploaded with mrt_scene_upload_lbvh_exact (both shaders walk the second tree)")
     args = ap.parse_args()
     from raytracing_amd import binding
     binding.LIB_PATH = os.path.join(ROOT, "raytracing_amd", "libmrt_prof.so")
@@ -58,7 +59,7 @@ def main():
                               "refl": refl, "refr": refr, "rindex": rindex})
             scene["meshes"] = parts
     rt = Raytracer(args.w, args.h, device=0)
-    rt.build_bvh(scene, lbvh=args.gpu_tree)
+    rt.build_bvh(scene, lbvh="exact" if args.two_trees else args.gpu_tree)
     if objects is not None:
         rt.set_objects(objects)
     fb = torch.zeros((args.h, args.w), dtype=torch.int32, device="cuda")
