@@ -21,6 +21,7 @@ def soups(n_scenes, seed):
     W, H = 192, 128
     rt = Raytracer(W, H, device=0)
     worst = 0.0
+    walked = [0, 0]
     for i in range(n_scenes):
         n = int(rng.integers(1, 6000))
         s = scene_io.soup_scene(n, seed=int(rng.integers(1, 1 << 30)))
@@ -54,6 +55,8 @@ def soups(n_scenes, seed):
             cam = oracle_lib.lookat(tuple(pos), tuple(rng.uniform([-20, -2, -43], [20, 2, -3]).astype(np.float32)))
             for mode in (0, 1):
                 fb, ids = rt.render(cam, mode=mode)
+                if TWO_TREES:
+                    walked[0] += rt.second_tree_use()[0]; walked[1] += 1
                 ref = ora.render(cam, W, H, mode=mode)
                 a = fb.view(np.uint8).reshape(-1, 4).astype(np.int16)
                 b = ref["fb"].view(np.uint8).reshape(-1, 4).astype(np.int16)
@@ -63,6 +66,8 @@ def soups(n_scenes, seed):
                     print("soup %d (n=%d, seed %d) mode %d: ids differ on %d rays, %.5f of pixels beyond 1/255" % (
                         i, n, seed, mode, int((ids != ref["ids"]).sum()), frac))
                     return 1
+    if TWO_TREES:
+        print("two trees: %d of %d frames walked a second tree (soups that fit the LDS have one)" % (walked[0], walked[1]))
     print("parity_fuzz: %d random soups x 2 poses x 2 shaders: hit ids identical, packet pixels identical, worst recursive "
           "fraction beyond 1/255: %.6f" % (n_scenes, worst))
     return 0
