@@ -885,7 +885,10 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
         int fstack = 0;
         bool fits = false;
         const int first_cost = env_int("MRT_SECOND_TREE_COST", 0);
+        // (the triangles alone, with the fewest nodes a tree of leaves of eight can have, must fit: otherwise no build is tried)
+        const bool hopeless = resident_lds_bytes((int)(B.n_tris / 4 + 3), (int)B.n_tris, c->stack_entries, false) + 256 > (size_t)kLdsBudget;
         for (float inner_cost : {first_cost > 0 ? (float)first_cost * 0.1f : 1.5f, 2.0f, 2.5f, 3.0f, 3.5f, 4.0f, 5.0f, 6.0f, 8.0f, 12.0f, 20.0f}) {
+            if (hopeless) break;
             if (!build_lbvh_device(T, c->stream, err, inner_cost)) return fail(c, MRT_E_HIP, err);
             fslots = (size_t)T.pool_ptr + 1;
             fstack = std::max(T.max_depth + 2, c->stack_entries);        // the waves' stacks serve walks of either tree
