@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--pose", default="P0")
     ap.add_argument("--only", default="", help="packet|recursive")
     ap.add_argument("--lights", default="", help="0|1: only this light count")
+    ap.add_argument("--one-tree", action="store_true", help="upload with mrt_scene_upload (the reference's tree alone) instead of mrt_scene_upload_lbvh_exact")
     ap.add_argument("--walk", type=float, default=0.0,
                     help="move the camera this many units sideways every frame (the frame loop walks 10 units/s, game.cpp:57-62)")
     ap.add_argument("--opaque", action="store_true", help="set refl = refr = 0 on every mesh (primary and shadow rays only)")
@@ -35,7 +36,7 @@ def main():
         cam.set_position((6, 3, 12))
         cam.look_at((0, 0, 0))
     rt = Raytracer(args.w, args.h, device=0)
-    rt.build_bvh(scene)
+    rt.build_bvh(scene, lbvh=False if args.one_tree else "exact")
     fb = torch.zeros((args.h, args.w), dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream()
     one_light = np.float32([[0, 5, 0, 1, 1, 1, 1]])
