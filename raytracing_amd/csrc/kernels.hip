@@ -253,8 +253,8 @@ __device__ __forceinline__ void slab_div_pair(v4f l0, v4f l1, v4f r0, v4f r1, co
 // dismiss a box that holds a hit -- so a quotient (b - O) / D is one fused multiply-add, b * r - ro with r = 1 / D and
 // ro = O * r: off by 2^-24 (|O| |r| + |quotient|) at most, while the boxes stand back by 2^-16 of the scene's largest
 // coordinate, times |r| in the quotient -- sixty times the error for an origin within SceneDev::reach (64 scene sizes).
-// The caller sees to that and to r being an ordinary number (ranges of the exact-division shortcut).  12 operations
-// for the twelve quotients instead of 84.
+// The caller sees to that (within_reach) and to r being an ordinary number (make_ray_second_tree).  12 operations for
+// the twelve quotients instead of 84.
 __device__ __forceinline__ void slab_mul_pair(v4f l0, v4f l1, v4f r0, v4f r1, const RayDiv& R, f3 ro, float t,
                                               bool& leftN, bool& rightN, float& tNear, float& tNear2) {
     float tFar, tFar2;
@@ -264,6 +264,27 @@ __device__ __forceinline__ void slab_mul_pair(v4f l0, v4f l1, v4f r0, v4f r1, co
     leftN = slab_pass(tNear, tFar, t);
     rightN = slab_pass(tNear2, tFar2, t);
 }
+
+// The ray constants for that: a reciprocal that is an ordinary number on every axis.  Where 1 / D is infinite or beyond
+// 2^60 (the ray runs along the axis' slabs: it moves less than 2^-52 scene sizes across them on its way through the
+// scene) +-2^60 stands in: a box whose slab holds the origin, with the margin its faces stand back by, then spans
+// parameters from below -2^44 to above 2^44 scene sizes on that axis, more than any hit's distance, and a slab that
+// does not hold the origin can hold no hit of this ray.  No product overflows for coordinates up to 2^30 (the second
+// tree is only kept for such scenes: mrt_scene_upload_lbvh_exact) and origins within SceneDev::reach.
+__device__ __forceinline__ float second_tree_recip(float d) {
+    const float r = 1.0f / d;
+    return fabsf(r) <= 0x1p60f ? r : __builtin_copysignf(0x1p60f, d);
+}
+__device__ __forceinline__ RayDiv make_ray_second_tree(f3 O, f3 D) {
+    RayDiv R;
+    R.O = O; R.D = D;
+    R.r = {second_tree_recip(D.x), second_tree_recip(D.y), second_tree_recip(D.z)};
+    R.shortcut = true;
+    return R;
+}
+// may a ray from O walk the second tree (slab_mul_pair)?
+template <class SC>
+__device__ __forceinline__ bool within_reach(const SC& sc, f3 O) { return fabsf(O.x) <= sc.reach && fabsf(O.y) <= sc.reach && fabsf(O.z) <= sc.reach; }
 
 // The two child tests of a shadow ray (t = INFINITY, so `tNear < t` always holds) decided from
 // interval bounds, for rays and scenes inside the ranges of the exact-division shortcut.
@@ -685,9 +706,9 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
         if (!slab_mul(xyz(root0), xyz(root1), O, D, t, tn)) return false;
     }
     MRT_TICK(wd, 2);
-    const RayDiv R = make_ray_div(O, D, coords_ok);
+    const RayDiv R = EXACT ? make_ray_second_tree(O, D) : make_ray_div(O, D, coords_ok);      // (EXACT: the caller has checked within_reach)
     const f3 ro = R.O * R.r;      // (EXACT: slab_mul_pair)
-    const bool shortcut = __all(R.shortcut && (!EXACT || (fabsf(O.x) <= sc.reach && fabsf(O.y) <= sc.reach && fabsf(O.z) <= sc.reach)));
+    const bool shortcut = EXACT || __all(R.shortcut);
     // groups of a long leaf may be skipped for rays whose reciprocal direction is an ordinary number on every axis
     const bool may_skip = sc.has_groups() && skip_ok && fabsf(R.r.x) < INFINITY && fabsf(R.r.y) < INFINITY && fabsf(R.r.z) < INFINITY;
     int sp = 0;
@@ -702,8 +723,8 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
             const v4f l0 = pair[0], l1 = pair[1], r0 = pair[2], r1 = pair[3];
             bool leftN, rightN;
             float tNear, tNear2;
-            if (EXACT && shortcut) slab_mul_pair(l0, l1, r0, r1, R, ro, t * kExactCull, leftN, rightN, tNear, tNear2);
-            else slab_div_pair(l0, l1, r0, r1, R, shortcut, EXACT ? t * kExactCull : t, leftN, rightN, tNear, tNear2);
+            if constexpr (EXACT) slab_mul_pair(l0, l1, r0, r1, R, ro, t * kExactCull, leftN, rightN, tNear, tNear2);
+            else slab_div_pair(l0, l1, r0, r1, R, shortcut, t, leftN, rightN, tNear, tNear2);
             // raytracer.cpp:1239-1262 as selects: go right when only the right child passes, or when
             // both pass and the right one is entered first (tNear2 < tNear); the other passing
             // child, if any, is deferred; with no passing child the next deferred node is taken.
@@ -817,9 +838,9 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
     const bool gate = take_part && slab_mul(xyz(root0), xyz(root1), O, D, INFINITY, tn);   // D, not 1/D (raytracer.cpp:947)
     unsigned long long m = __ballot(gate);
     if (m == 0) return false;
-    const RayDiv R = make_ray_div(O, D, coords_ok);
+    const RayDiv R = EXACT ? make_ray_second_tree(O, D) : make_ray_div(O, D, coords_ok);      // (EXACT: the caller has checked within_reach)
     const f3 ro = R.O * R.r;      // (EXACT: slab_mul_pair)
-    const bool shortcut = !__any(take_part && !(R.shortcut && (!EXACT || (fabsf(O.x) <= sc.reach && fabsf(O.y) <= sc.reach && fabsf(O.z) <= sc.reach))));
+    const bool shortcut = EXACT || !__any(take_part && !R.shortcut);
     const bool r_ok = skip_ok && fabsf(R.r.x) < INFINITY && fabsf(R.r.y) < INFINITY && fabsf(R.r.z) < INFINITY;
     float t = INFINITY;
     Hit h;
@@ -890,7 +911,7 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
             MRT_TICK(wd, 4);
             bool leftN, rightN;
             float nl = 0.0f, nr = 0.0f;          // entry distances (estimates will do: they only order the two children)
-            if (EXACT && shortcut) {
+            if constexpr (EXACT) {
                 slab_mul_pair(l0, l1, r0, r1, R, ro, INFINITY, leftN, rightN, nl, nr);
             } else {
                 const bool sure = shortcut && slab_pair_shadow_interval(l0, l1, r0, r1, R, leftN, rightN, nl, nr);
@@ -1046,7 +1067,8 @@ __device__ __forceinline__ void direct_light(const SC& sc, const SceneDev& S, bo
         const float4 lp = S.lights[2 * i];
         const f3 L = lit ? normalize(xyz(lp) - hit) : f3{0.0f, 0.0f, 1.0f};
         const bool off_plane = not_grazing(L, s.normal);
-        bool unsure = EXACT && lit && !off_plane;           // (such a shadow ray goes straight to the reference's tree)
+        bool unsure = false;           // (a shadow ray nearly in its surface's plane, or from too far away, goes straight to the reference's tree)
+        if constexpr (EXACT) unsure = lit && !(off_plane && within_reach(sc, hit));
         bool occluded = occluded_wave<TEAM, EXACT>(sc, S.n_tris, S.coords_ok != 0, hit, L, lit && !unsure, off_plane, lane, wd, &unsure);
         if constexpr (EXACT) {
             if (__any(unsure)) {          // those lanes' shadow rays once more, through the reference's tree
@@ -1119,7 +1141,8 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
         bool isHit = false;
         MRT_PHASE_BEGIN(wd);
         // (EXACT: a ray nearly in the plane of the surface it starts from -- see not_grazing -- goes straight to the reference's tree)
-        bool unsure = EXACT && tracing && !skip_ok;
+        bool unsure = false;
+        if constexpr (EXACT) unsure = tracing && !(skip_ok && within_reach(sc, O));
         if (tracing && !unsure) isHit = traverse_nearest<TEAM, EXACT>(sc, S.n_tris, S.coords_ok != 0, O, D, skip_ok, t, h, stack, wd, lane, &unsure);
         if constexpr (EXACT) {
             if (__any(unsure)) {          // not certainly the reference's result: BVH::Traverse itself on the reference's tree

@@ -946,7 +946,7 @@ static int scene_upload(mrt_ctx* c, const mrt_mesh* meshes, int n_meshes, const 
             c->fast.coords_ok = fcoords ? 1 : 0;
             c->fast.reach = 64.0f * largest;
             c->fast.stack_entries = fstack;
-            c->fast.ok = true;
+            c->fast.ok = fcoords;       // (coordinates beyond 2^30 or below 2^-27: kernels.hip, make_ray_second_tree; such a scene keeps one tree)
             stage("second tree packed");
         }
     }
