@@ -1295,7 +1295,10 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
         MRT_PHASE_BEGIN(wd);
         if constexpr (EXACT) {
             bool unsure = false;
-            traverse_packet<true>(sc, S.n_tris, O, D, rD, t, h, lane, wd, &unsure);
+            // (the second tree's boxes take a reciprocal that is an ordinary number on every axis, see make_ray_second_tree:
+            // one instance of the walk for all packets; the camera is within SceneDev::reach, the launcher's condition)
+            const f3 rD2 = {second_tree_recip(D.x), second_tree_recip(D.y), second_tree_recip(D.z)};
+            if (S.n_tris != 0) traverse_packet_impl<true, true>(sc, O, D, rD2, t, h, lane, wd, &unsure);
             bool undecided;
             if (h.tri >= 0 && !hit_is_the_references<true>(sc.leaf_box, h.tri, O, rD, t, true, undecided)) unsure = true;
             if (__any(unsure)) {          // the packet once more, through the reference's tree: what a ray of a packet tests depends on the others

@@ -338,7 +338,10 @@ int render_common(mrt_ctx* c, const float cam[16], uint32_t flags, int y_begin, 
     }
     // a scene with a second tree (mrt_scene_upload_lbvh_exact): the recursive shader walks that one in the persistent kernel,
     // the packet path in the one-wave-per-tile kernel
-    const bool second_tree = c->fast.ok && c->scene.n_objects == 0 && env_int("MRT_TWO_TREES", 1) != 0;
+    // (its boxes stand back from their triangles by a margin that covers the rounding of the box tests for eyes within
+    // `reach` of the origin: kernels.hip, slab_mul_pair; frames from farther away walk the reference's tree)
+    const bool eye_in_reach = fabsf(cam[12]) <= c->fast.reach && fabsf(cam[13]) <= c->fast.reach && fabsf(cam[14]) <= c->fast.reach;
+    const bool second_tree = c->fast.ok && c->scene.n_objects == 0 && eye_in_reach && env_int("MRT_TWO_TREES", 1) != 0;
     const bool two_trees = second_tree && mode == (int)MRT_MODE_RECURSIVE;
     bool resident = two_trees || (c->resident && mode == (int)MRT_MODE_RECURSIVE && c->scene.n_objects == 0);
     if (env_int("MRT_RESIDENT_PACKET", 0)) resident = c->resident && c->scene.n_objects == 0;
