@@ -710,7 +710,8 @@ __device__ __forceinline__ bool traverse_nearest(const SC& sc, int n_tris, bool 
     const f3 ro = R.O * R.r;      // (EXACT: slab_mul_pair)
     const bool shortcut = EXACT || __all(R.shortcut);
     // groups of a long leaf may be skipped for rays whose reciprocal direction is an ordinary number on every axis
-    const bool may_skip = sc.has_groups() && skip_ok && fabsf(R.r.x) < INFINITY && fabsf(R.r.y) < INFINITY && fabsf(R.r.z) < INFINITY;
+    const bool may_skip = !EXACT && sc.has_groups() && skip_ok &&      // (a second tree has no group boxes)
+                          fabsf(R.r.x) < INFINITY && fabsf(R.r.y) < INFINITY && fabsf(R.r.z) < INFINITY;
     int sp = 0;
     uint32_t first = wbits(root0), count = wbits(root1);
     bool alive = true;
@@ -877,7 +878,7 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
                     if (!__any(h.tri < 0 && ((m >> lane) & 1ull))) break;
                 }
             } else if ((m >> lane) & 1ull) {
-                if (SC::kShadowGroups && sc.has_groups() && count >= (uint32_t)MRT_GROUP_MIN) {
+                if (!EXACT && SC::kShadowGroups && sc.has_groups() && count >= (uint32_t)MRT_GROUP_MIN) {
                     walk_leaf_by_groups<false>(sc, first, count, O, R.r, r_ok, t, wd, [&](uint32_t k) {
                         MRT_TICK(wd, 5);
                         if (h.tri < 0) { tri_test_shared(sc, k, O, D, t, h, wd, Tie{nullptr}); vet(); }
