@@ -343,6 +343,13 @@ struct Tie {
 // -- so a hit on a triangle of a leaf the ray misses is dropped and the walk goes on; only 0/0 leaves it undecided
 // (then the lane's shadow ray too goes through the reference's tree: direct_light).
 constexpr float kExactCull = 1.0f + 0x1p-10f;
+// Test build (make retrace: libmrt_retrace.so): EVERY ray of a frame through a second tree counts as unsure, so the walks
+// through the reference's tree that normally serve a handful of rays per frame render the whole frame.
+#ifdef MRT_FORCE_RETRACE
+constexpr bool kForceRetrace = true;
+#else
+constexpr bool kForceRetrace = false;
+#endif
 // undecided: a quotient of the leaf's box test is 0/0 (the ray runs inside a face of the box)
 // PACKET: the box test as the packet traversal computes it (raytracer.cpp:1372-1376: products with the ray's reciprocal
 // direction rD, passed in D's place; 0 * inf is its 0/0).  The argument is the same: a ray that passes the leaf's box
@@ -1069,7 +1076,7 @@ __device__ __forceinline__ void direct_light(const SC& sc, const SceneDev& S, bo
         const f3 L = lit ? normalize(xyz(lp) - hit) : f3{0.0f, 0.0f, 1.0f};
         const bool off_plane = not_grazing(L, s.normal);
         bool unsure = false;           // (a shadow ray nearly in its surface's plane, or from too far away, goes straight to the reference's tree)
-        if constexpr (EXACT) unsure = lit && !(off_plane && within_reach(sc, hit));
+        if constexpr (EXACT) unsure = lit && (kForceRetrace || !(off_plane && within_reach(sc, hit)));
         bool occluded = occluded_wave<TEAM, EXACT>(sc, S.n_tris, S.coords_ok != 0, hit, L, lit && !unsure, off_plane, lane, wd, &unsure);
         if constexpr (EXACT) {
             if (__any(unsure)) {          // those lanes' shadow rays once more, through the reference's tree
@@ -1143,7 +1150,7 @@ __device__ __forceinline__ f4 shade_recursive(const SC& sc, const SceneDev& S, f
         MRT_PHASE_BEGIN(wd);
         // (EXACT: a ray nearly in the plane of the surface it starts from -- see not_grazing -- goes straight to the reference's tree)
         bool unsure = false;
-        if constexpr (EXACT) unsure = tracing && !(skip_ok && within_reach(sc, O));
+        if constexpr (EXACT) unsure = tracing && (kForceRetrace || !(skip_ok && within_reach(sc, O)));
         if (tracing && !unsure) isHit = traverse_nearest<TEAM, EXACT>(sc, S.n_tris, S.coords_ok != 0, O, D, skip_ok, t, h, stack, wd, lane, &unsure);
         if constexpr (EXACT) {
             if (__any(unsure)) {          // not certainly the reference's result: BVH::Traverse itself on the reference's tree
@@ -1295,7 +1302,7 @@ __device__ __forceinline__ void render_tile(const SC& sc, const SceneDev& S, con
         float t = 100000000;
         MRT_PHASE_BEGIN(wd);
         if constexpr (EXACT) {
-            bool unsure = false;
+            bool unsure = kForceRetrace;
             // (the second tree's boxes take a reciprocal that is an ordinary number on every axis, see make_ray_second_tree:
             // one instance of the walk for all packets; the camera is within SceneDev::reach, the launcher's condition)
             const f3 rD2 = {second_tree_recip(D.x), second_tree_recip(D.y), second_tree_recip(D.z)};
@@ -1635,7 +1642,7 @@ __global__ __launch_bounds__(kResidentThreads, MRT_RESIDENT_WAVES) void render_t
     __syncthreads();
     const SceneLds sc{l_nodes, l_a, l_b, l_c, l_g, S.triG != nullptr, S.place, reinterpret_cast<const v4f*>(S.leaf_box), S.reach,
                       SceneGlobalT<false>{reinterpret_cast<const v4f*>(S.ref_nodes), reinterpret_cast<const v4f*>(S.ref_triA), reinterpret_cast<const v4f*>(S.ref_triB),
-                                          reinterpret_cast<const v2f*>(S.ref_triC), nullptr, nullptr, S.ref_place}};
+                                          reinterpret_cast<const v2f*>(S.ref_triC), nullptr, reinterpret_cast<const v4f*>(S.ref_triM), S.ref_place}};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #ifdef MRT_LOOP_COUNTS
     const unsigned long long t_ready = __builtin_readcyclecounter();

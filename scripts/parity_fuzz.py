@@ -20,6 +20,7 @@ def soups(n_scenes, seed):
     rng = np.random.default_rng(seed)
     W, H = 192, 128
     rt = Raytracer(W, H, device=0)
+    rt1 = Raytracer(W, H, device=0)          # two trees: the same scenes with the reference's tree alone, held bit for bit
     worst = 0.0
     walked = [0, 0]
     for i in range(n_scenes):
@@ -44,12 +45,15 @@ def soups(n_scenes, seed):
         ora.build_bvh()
         ora.set_threads(16)
         rt.build_bvh(s, lbvh="exact" if TWO_TREES else False)
+        if TWO_TREES:
+            rt1.build_bvh(s)
         nl = int(rng.integers(0, 4))
         L = np.zeros((nl, 7), np.float32)
         L[:, :3] = rng.uniform([-20, -3, -45], [20, 8, 0], (nl, 3))
         L[:, 3:] = rng.uniform(0, 1, (nl, 4))
         ora.set_lights(L)
         rt.set_lights(L)
+        rt1.set_lights(L)
         for _ in range(2):
             pos = rng.uniform([-20, -3, -40], [20, 3, 2]).astype(np.float32)
             cam = oracle_lib.lookat(tuple(pos), tuple(rng.uniform([-20, -2, -43], [20, 2, -3]).astype(np.float32)))
@@ -57,6 +61,11 @@ def soups(n_scenes, seed):
                 fb, ids = rt.render(cam, mode=mode)
                 if TWO_TREES:
                     walked[0] += rt.second_tree_use()[0]; walked[1] += 1
+                    c2 = rt.ray_counts()
+                    fb1, ids1 = rt1.render(cam, mode=mode)
+                    if not (np.array_equal(fb, fb1) and np.array_equal(ids, ids1) and c2 == rt1.ray_counts()):
+                        print("soup %d (n=%d, seed %d) mode %d: two trees against one: %d pixels, %d hit ids differ" % (i, n, seed, mode, int((fb != fb1).sum()), int((ids != ids1).sum())))
+                        return 1
                 ref = ora.render(cam, W, H, mode=mode)
                 a = fb.view(np.uint8).reshape(-1, 4).astype(np.int16)
                 b = ref["fb"].view(np.uint8).reshape(-1, 4).astype(np.int16)
@@ -100,6 +109,11 @@ def main():
     rts = {s: Raytracer(s[0], s[1], device=0) for s in sizes}
     for rt in rts.values():
         rt.build_bvh(scene, lbvh="exact" if TWO_TREES else gpu_tree)
+    # two trees: also held, bit for bit, to the same library on the reference's tree alone (the oracle's bar lets a
+    # recursive pixel differ by 1/255)
+    ones = {s: Raytracer(s[0], s[1], device=0) for s in sizes} if TWO_TREES else {}
+    for rt in ones.values():
+        rt.build_bvh(scene)
     worst = 0.0
     rays = id_diffs = px_diffs = frames_off = 0
     by_mode = {0: [0, 0], 1: [0, 0]}
@@ -141,6 +155,12 @@ def main():
                 print("pose %d mode %d: pixels differ (%.5f beyond 1/255; pos %s target %s)" % (i, mode, frac, pos, target))
                 return 1
             c = rt.ray_counts()
+            if TWO_TREES:
+                ones[(W, H)].set_lights(light)
+                fb1, ids1 = ones[(W, H)].render(cam, mode=mode, spp_grid=g)
+                if not (np.array_equal(fb, fb1) and np.array_equal(ids, ids1) and c == ones[(W, H)].ray_counts()):
+                    print("pose %d mode %d: two trees against one: %d pixels, %d hit ids differ (pos %s target %s)" % (i, mode, int((fb != fb1).sum()), int((ids != ids1).sum()), pos, target))
+                    return 1
             if TWO_TREES and mode == 1:
                 walked, again = rt.second_tree_use()
                 second[0] += walked; second[1] += again

@@ -4,6 +4,10 @@ still be the reference's -- hit IDs, pixels and ray counts are held to those of 
 tree (bit for bit: the arithmetic per ray is the same, only the tree differs) and to the CPU oracle (the usual bar).
 mrt_get_second_tree_use shows that the second tree was really walked, and how many rays had to ask the first.
 """
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -179,3 +183,15 @@ def test_device_frames_shares_and_the_entry_point_without_allocations(maze_scene
     got = two.render(cam, mode=MODE_RECURSIVE, extra_flags=binding.FLAG_FRAME_ORDER)
     assert np.array_equal(got[0].view(np.int32), want.cpu().numpy())
     one.close(); two.close()
+
+
+def test_every_ray_through_the_walks_of_the_references_tree():
+    """The walks a two-tree frame falls back on serve a handful of rays per frame; libmrt_retrace.so (the same sources,
+    every ray counted as unsure) renders whole frames with them: tests/retrace_check.py, in a process of its own because a
+    process binds one library."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "raytracing_amd", "libmrt_retrace.so")
+    assert os.path.exists(lib), "libmrt_retrace.so is not built (make -C raytracing_amd/csrc retrace)"
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "retrace_check.py")], env=dict(os.environ, MRT_LIB=lib),
+                       capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0 and "retrace_check OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
