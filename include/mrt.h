@@ -101,7 +101,9 @@ int mrt_scene_upload_lbvh(mrt_ctx* ctx, const mrt_mesh* meshes, int n_meshes,
 /* Raytracer::BuildBVH(meshList) (game.cpp:34; raytracer.cpp:670-673) with two trees: everything mrt_scene_upload
  * does -- the reference's own tree (raytracer.cpp:897-1203) serves every call as it does there --, and beside it the
  * GPU-built tree of mrt_scene_upload_lbvh over the same triangles.  Frames of the recursive shader and of the packet
- * path (MRT_MODE_RECURSIVE, MRT_MODE_PACKET; a scene that fits the LDS, no analytic primitives) walk the second tree,
+ * path (MRT_MODE_RECURSIVE, MRT_MODE_PACKET; a scene that fits the LDS, with coordinates of ordinary size -- zero or
+ * between 2^-27 and 2^30 --, no analytic primitives, the eye within 64 times the scene's largest coordinate of the
+ * origin; any other frame walks the reference's tree as after mrt_scene_upload) walk the second tree,
  * which is the faster one, and report what BVH::Traverse and BVH::TraverseRayPacket (raytracer.cpp:1204-1264,
  * 1328-1464) report on the reference's tree: a ray's result is taken from the second tree only where it can be shown to
  * be the reference's (no other triangle as near to within rounding, and the ray passes the hit triangle's leaf box of
