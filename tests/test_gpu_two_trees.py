@@ -195,3 +195,13 @@ def test_every_ray_through_the_walks_of_the_references_tree():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "retrace_check.py")], env=dict(os.environ, MRT_LIB=lib),
                        capture_output=True, text=True, timeout=110)
     assert r.returncode == 0 and "retrace_check OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_random_and_axis_aligned_cameras_on_two_trees():
+    """A short run of the campaigns behind the parity figures: random poses and soups through a two-tree upload against
+    the oracle and, bit for bit, against the one-tree upload (scripts/parity_fuzz.py --two-trees); axis-aligned cameras,
+    whose centre rays have a direction component of exactly zero (scripts/two_trees_axis.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for args in (["parity_fuzz.py", "--two-trees", "60", "5"], ["parity_fuzz.py", "--two-trees", "--soups", "20", "6"], ["two_trees_axis.py", "--oracle", "60", "3"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", args[0])] + args[1:], capture_output=True, text=True, timeout=110)
+        assert r.returncode == 0, " ".join(args) + ": " + r.stdout[-1500:] + r.stderr[-1500:]
