@@ -23,6 +23,7 @@ def soups(n_scenes, seed):
     rt1 = Raytracer(W, H, device=0)          # two trees: the same scenes with the reference's tree alone, held bit for bit
     worst = 0.0
     walked = [0, 0]
+    any_diff = [0, 0]          # recursive pixels that differ from the oracle's at all | compared
     for i in range(n_scenes):
         n = int(rng.integers(1, 6000))
         s = scene_io.soup_scene(n, seed=int(rng.integers(1, 1 << 30)))
@@ -71,6 +72,8 @@ def soups(n_scenes, seed):
                 b = ref["fb"].view(np.uint8).reshape(-1, 4).astype(np.int16)
                 frac = float((np.abs(a - b).max(axis=1) > 1).mean())
                 worst = max(worst, frac)
+                if mode == 1:
+                    any_diff[0] += int((fb != ref["fb"]).sum()); any_diff[1] += fb.size
                 if not np.array_equal(ids, ref["ids"]) or (mode == 0 and not np.array_equal(fb, ref["fb"])) or frac > 0.001:
                     print("soup %d (n=%d, seed %d) mode %d: ids differ on %d rays, %.5f of pixels beyond 1/255" % (
                         i, n, seed, mode, int((ids != ref["ids"]).sum()), frac))
@@ -78,7 +81,7 @@ def soups(n_scenes, seed):
     if TWO_TREES:
         print("two trees: %d of %d frames walked a second tree (soups that fit the LDS have one)" % (walked[0], walked[1]))
     print("parity_fuzz: %d random soups x 2 poses x 2 shaders: hit ids identical, packet pixels identical, worst recursive "
-          "fraction beyond 1/255: %.6f" % (n_scenes, worst))
+          "fraction beyond 1/255: %.6f; recursive pixels that differ from the oracle's at all: %d of %d" % (n_scenes, worst, any_diff[0], any_diff[1]))
     return 0
 
 
@@ -118,6 +121,7 @@ def main():
     rays = id_diffs = px_diffs = frames_off = 0
     by_mode = {0: [0, 0], 1: [0, 0]}
     second = [0, 0]
+    any_diff = [0, 0]          # recursive pixels that differ from the oracle's at all | compared
     for i in range(n_poses):
         W, H = sizes[i % len(sizes)]
         rt = rts[(W, H)]
@@ -151,6 +155,8 @@ def main():
             b = ref["fb"].view(np.uint8).reshape(-1, 4).astype(np.int16)
             frac = float((np.abs(a - b).max(axis=1) > 1).mean())
             worst = max(worst, frac)
+            if mode == 1:
+                any_diff[0] += int((fb != ref["fb"]).sum()); any_diff[1] += fb.size
             if (mode == 0 and not np.array_equal(fb, ref["fb"])) or frac > 0.001:
                 print("pose %d mode %d: pixels differ (%.5f beyond 1/255; pos %s target %s)" % (i, mode, frac, pos, target))
                 return 1
@@ -171,7 +177,8 @@ def main():
               "differ from the oracle's, in %d frames; packet shader %d ids %d pixels, recursive shader %d ids %d pixels%s" %
               (n_poses, rays, id_diffs, px_diffs, frames_off, by_mode[0][0], by_mode[0][1], by_mode[1][0], by_mode[1][1], ""))
         return 0
-    print("parity_fuzz: %d poses x 2 shaders: hit ids identical, packet pixels identical, worst recursive fraction beyond 1/255: %.6f" % (n_poses, worst))
+    print("parity_fuzz: %d poses x 2 shaders: hit ids identical, packet pixels identical, worst recursive fraction beyond 1/255: %.6f; "
+          "recursive pixels that differ from the oracle's at all: %d of %d" % (n_poses, worst, any_diff[0], any_diff[1]))
     return 0
 
 
