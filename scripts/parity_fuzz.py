@@ -25,6 +25,8 @@ def soups(n_scenes, seed):
     walked = [0, 0]
     any_diff = [0, 0]          # recursive pixels that differ from the oracle's at all | compared
     for i in range(n_scenes):
+        if i and i % 100 == 0:
+            print("... %d soups" % i, flush=True)
         n = int(rng.integers(1, 6000))
         s = scene_io.soup_scene(n, seed=int(rng.integers(1, 1 << 30)))
         m = s["meshes"][0]
@@ -123,6 +125,8 @@ def main():
     second = [0, 0]
     any_diff = [0, 0]          # recursive pixels that differ from the oracle's at all | compared
     for i in range(n_poses):
+        if i and i % 1000 == 0:
+            print("... %d poses" % i, flush=True)
         W, H = sizes[i % len(sizes)]
         rt = rts[(W, H)]
         pos = rng.uniform([-19, -0.9, -21], [19, 6, 21]).astype(np.float32)

@@ -48,6 +48,8 @@ def main():
     rng = np.random.default_rng(seed)
     again = walked = 0
     for i in range(n):
+        if i and i % 500 == 0:
+            print("... %d cameras" % i, flush=True)
         pos = rng.uniform([-19, -0.9, -21], [19, 6, 21]).astype(np.float32)
         if i % 3 == 0:
             pos = np.round(pos * 2) / 2
