@@ -865,12 +865,20 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
         }
     };
     LaneStack4 work;
-    work.push(lane, wbits(root0), wbits(root1), m);
+    // The entry in hand {first, count, m} (wave-uniform: scalar registers); an inner node goes on with one of its
+    // children at once and defers only the other, so the list is touched once per node with two passing children
+    // instead of three times per node.
+    auto uniform = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
+    uint32_t first = uniform(wbits(root0)), count = uniform(wbits(root1));
+    bool in_hand = true;
     unsigned long long found = 0;
-    while (work.sp > 0) {
+    for (;;) {
         if (wd.expired(16)) break;
-        uint32_t first, count;
-        work.pop(first, count, m);
+        if (!in_hand) {
+            if (work.sp == 0) break;
+            work.pop(first, count, m);
+        }
+        in_hand = false;
         m &= ~found;
         if (m == 0) continue;
         MRT_TICK(wd, 3);
@@ -931,8 +939,12 @@ __device__ __forceinline__ bool occluded_wave(const SC& sc, int n_tris, bool coo
             const unsigned long long ml = __ballot(leftN) & m, mr = __ballot(rightN) & m;
             // (Any order gives the same answer.  Entering first the child that most of the rays reach first, the likelier
             // one to block them soon, was measured: 2.7 % slower.)
-            if (mr) work.push(lane, wbits(r0), wbits(r1), mr);
-            if (ml) work.push(lane, wbits(l0), wbits(l1), ml);
+            if (ml) {
+                if (mr) work.push(lane, wbits(r0), wbits(r1), mr);
+                first = uniform(wbits(l0)); count = uniform(wbits(l1)); m = ml; in_hand = true;
+            } else if (mr) {
+                first = uniform(wbits(r0)); count = uniform(wbits(r1)); m = mr; in_hand = true;
+            }
         }
     }
     if constexpr (EXACT && TEAM) *unsure = ((__ballot(*unsure) >> (lane & 48)) & 0xffffull) != 0;       // the members carry one ray
